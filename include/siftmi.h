@@ -1,0 +1,144 @@
+/*
+ * siftmi.h -- C ABI of libsiftmi.so, the MI355X (gfx950) SIFT hot path.
+ *
+ * This is the drop-in boundary for the reference's SiftPlan.keypoints() / MatchPlan.match()
+ * path.  The reference (pierrepaleo/sift_pyocl) has no FFI of its own: its boundary is
+ * PyOpenCL -- pyopencl.Program(...).build() (sift-src/plan.py:364), kernel launches
+ * program.kernel(queue, global, local, *args) (e.g. plan.py:586-591, match.py:246-255),
+ * pyopencl.array allocation (plan.py:276-293) and blocking enqueue_copy read-backs
+ * (plan.py:452-468, 642, 751; match.py:258-261).  Each entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions: every function returns 0 on success, a negative SIFTMI_E* code otherwise, with a
+ * message retrievable from siftmi_last_error() (thread-local).  Handles are opaque, bound to one
+ * HIP device and one HIP stream, and must be used by one host thread at a time (the Python
+ * wrapper holds the reference's per-plan semaphore, plan.py:156,439 / match.py:117,215).
+ * "is_device" pointers are HIP device pointers on the plan's device; the call orders itself
+ * after work already submitted to the NULL stream by synchronising the device once on entry
+ * when a device pointer is passed.
+ */
+#ifndef SIFTMI_H
+#define SIFTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFTMI_OK 0
+#define SIFTMI_EINVAL (-1)   /* bad argument                       -> RuntimeError / AssertionError in Python */
+#define SIFTMI_ENOMEM (-2)   /* device or host allocation failed   -> MemoryError  (plan.py:365-366)           */
+#define SIFTMI_EDEVICE (-3)  /* HIP runtime error / no gfx950 GPU  -> RuntimeError                             */
+#define SIFTMI_ECAPACITY (-4)/* output buffer too small (results truncated, *n_out = number written)           */
+
+/* input pixel types accepted by SiftPlan (plan.py:99-106, 450-488) */
+enum siftmi_dtype {
+    SIFTMI_F32 = 0, SIFTMI_U8 = 1, SIFTMI_U16 = 2, SIFTMI_U32 = 3, SIFTMI_U64 = 4,
+    SIFTMI_I32 = 5, SIFTMI_I64 = 6, SIFTMI_F64 = 7, SIFTMI_RGB8 = 8
+};
+
+/* 144-byte keypoint record == SiftPlan.dtype_kp / MatchPlan.dtype_kp (plan.py:110-115, match.py:70-75),
+ * == t_keypoint of openCL/matching_cpu.cl:22-25 */
+typedef struct siftmi_keypoint {
+    float x, y, scale, angle;
+    uint8_t desc[128];
+} siftmi_keypoint;
+
+/* SIFT parameters read from sift_pyocl.param.par at call time (param.py:52-79) */
+typedef struct siftmi_params {
+    double init_sigma;    /* SiftPlan(init_sigma=) or par.InitSigma; Python double (plan.py:129-131) */
+    float peak_thresh;    /* par.PeakThresh  -> local_maxmin / interp_keypoint (plan.py:631, 648)    */
+    float edge_thresh0;   /* par.EdgeThresh1 -> kernel slot EdgeThresh0, octsize<=1 (plan.py:633)    */
+    float edge_thresh;    /* par.EdgeThresh  -> kernel slot EdgeThresh (plan.py:634)                 */
+    float ori_sigma;      /* par.OriSigma    (plan.py:681)                                           */
+    int32_t border_dist;  /* par.BorderDist  (plan.py:630)                                           */
+    int32_t octave_max;   /* 0 = every octave (reference behaviour, plan.py:213-224); >0 = extension */
+    int32_t pix_per_kp;   /* SiftPlan.PIX_PER_KP: kpsize = H*W / pix_per_kp (plan.py:109, 243)       */
+    int32_t reserved;
+} siftmi_params;
+
+typedef struct siftmi_plan siftmi_plan;
+typedef struct siftmi_matcher siftmi_matcher;
+
+/* ---- runtime ------------------------------------------------------------------------------
+ * replaces sift-src/clinit.py device enumeration (ocl.select_device, clinit.py:360-400) */
+int siftmi_device_count(void);
+int siftmi_device_name(int device_id, char *buf, int64_t buflen);
+const char *siftmi_last_error(void);
+const char *siftmi_version(void);
+
+/* ---- SiftPlan ------------------------------------------------------------------------------
+ * siftmi_plan_create    <- SiftPlan.__init__ (plan.py:117-201): sizes the pyramid (_calc_scales
+ *                          :213), allocates every device buffer (_allocate_buffers :268) and the six
+ *                          Gaussian tap vectors (_init_gaussian :308).
+ * siftmi_plan_keypoints <- SiftPlan.keypoints (plan.py:432-567) including _one_octave (:596-756) and
+ *                          _compact (:758-795); one host<->device synchronisation per image instead of
+ *                          >= 18 per octave.  Output order within the result is unspecified (as in the
+ *                          reference, whose kernels append through atomic_inc).
+ *                          image_dtype must be the plan's dtype or SIFTMI_F32 (plan.py:444 accepts both).
+ * siftmi_plan_get_minmax<- buffers["min"] / buffers["max"] (plan.py:286-287; read by alignment.py:345).
+ * siftmi_plan_profile   <- SiftPlan.log_profile (plan.py:826-847): "label\tms\n" lines of the last call.
+ */
+int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id,
+                       const siftmi_params *params, int32_t profile, siftmi_plan **out);
+int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsize, int64_t *bytes_allocated);
+int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
+int siftmi_plan_keypoints(siftmi_plan *plan, const void *image, int32_t image_dtype, int32_t image_is_device,
+                          siftmi_keypoint *out, int32_t out_is_device, int64_t capacity, int64_t *n_out,
+                          int32_t *overflow);
+int siftmi_plan_get_minmax(const siftmi_plan *plan, float *min_out, float *max_out);
+int siftmi_plan_profile(const siftmi_plan *plan, char *buf, int64_t buflen);
+/* device time (ms, hipEvent on the plan's stream) of the kernels of the last keypoints() call,
+ * excluding host<->device copies; requires profile=1 at creation */
+int siftmi_plan_last_kernel_ms(const siftmi_plan *plan, float *total_ms, float *blur_ms, int32_t *blur_launches,
+                               double *blur_pixels);
+int siftmi_plan_destroy(siftmi_plan *plan);
+
+/* ---- MatchPlan -----------------------------------------------------------------------------
+ * siftmi_match_create <- MatchPlan.__init__ (match.py:77-139)
+ * siftmi_match        <- MatchPlan.match (match.py:200-271) with the `matching` kernel
+ *                        (matching_cpu.cl:57-109): L1 distance, best/second-best, ratio test
+ *                        dist1/dist2 < ratio_th.  *n_out = pairs written (<= capacity); *n_total = pairs
+ *                        that passed (the reference silently drops the excess, match.py:252).
+ */
+int siftmi_match_create(int64_t size, int32_t device_id, int32_t profile, siftmi_matcher **out);
+int siftmi_match(siftmi_matcher *plan, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
+                 const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th,
+                 int32_t *pairs, int64_t capacity, int64_t *n_out, int64_t *n_total);
+int siftmi_match_last_kernel_ms(const siftmi_matcher *plan, float *ms);
+int siftmi_match_destroy(siftmi_matcher *plan);
+
+/* ---- per-stage entry points (host pointers in/out; golden-vector replay, one reference kernel each)
+ * gaussian.cl:56 | reductions.cl:62-241 + preprocess.cl:239 | convolution.cl:16,62 | algebra.cl:18 |
+ * image.cl:119 | image.cl:235 + algebra.cl:57 | image.cl:47 | orientation_cpu.cl:41 |
+ * keypoints_cpu.cl:36 | preprocess.cl:267 | preprocess.cl:53-223 */
+int siftmi_stage_gaussian_taps(float sigma, int32_t size, float *out);
+int siftmi_stage_minmax_normalize(int32_t device_id, const float *in, float *out, int32_t W, int32_t H,
+                                  float *min_out, float *max_out);
+int siftmi_stage_blur(int32_t device_id, const float *in, float *out, int32_t W, int32_t H,
+                      const float *taps, int32_t ntaps);
+int siftmi_stage_dog(int32_t device_id, const float *blur_a, const float *blur_b, float *out, int64_t n);
+/* blurs: 6 planes (H,W); out: (capacity,4) floats (peak,row,col,scale) for scales 1..3 */
+int siftmi_stage_local_maxmin(int32_t device_id, const float *blurs, int32_t W, int32_t H, int32_t octsize,
+                              const siftmi_params *params, float *out, int64_t capacity, int64_t *n_out);
+/* candidates (n,4) -> refined (peak,row,col,sigma) + detection scale, holes removed */
+int siftmi_stage_interp(int32_t device_id, const float *blurs, int32_t W, int32_t H, const float *cand, int64_t n,
+                        const siftmi_params *params, float *out, int32_t *out_scale, int64_t *n_out);
+int siftmi_stage_gradient(int32_t device_id, const float *img, float *grad, float *ori, int32_t W, int32_t H);
+/* refined (n,4)+scale -> oriented (x,y,sigma*oct,angle)+scale, extras appended (capacity rows) */
+int siftmi_stage_orientation(int32_t device_id, const float *blurs, int32_t W, int32_t H, int32_t octsize,
+                             const float *kps, const int32_t *kp_scale, int64_t n, const siftmi_params *params,
+                             float *out, int32_t *out_scale, int64_t capacity, int64_t *n_out);
+int siftmi_stage_descriptor(int32_t device_id, const float *blurs, int32_t W, int32_t H, int32_t octsize,
+                            const float *kps, const int32_t *kp_scale, int64_t n, uint8_t *desc);
+int siftmi_stage_shrink(int32_t device_id, const float *in, float *out, int32_t W, int32_t H);
+int siftmi_stage_convert(int32_t device_id, const void *in, int32_t in_dtype, float *out, int32_t W, int32_t H);
+/* device versions of the "siftmath v1" functions, elementwise over n floats (test hook) */
+int siftmi_stage_math(int32_t device_id, int32_t fn /*0 exp,1 exp2,2 sin,3 cos,4 atan2*/, const float *a,
+                      const float *b, float *out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -206,7 +206,7 @@ def keypoints(image, par=None, return_overflow=False):
 
 def match(kp1, kp2, ratio_th=np.float32(0.73 * 0.73), cap=None):
     kp1 = np.ascontiguousarray(kp1, dtype=dtype_kp); kp2 = np.ascontiguousarray(kp2, dtype=dtype_kp)
-    cap = cap if cap is not None else max(1, min(kp1.size, kp2.size))
+    cap = cap if cap is not None else max(1, kp1.size)
     pairs = np.full((cap, 2), -1, np.int32)
     n = lib().so_match(_p(kp1), C.c_int64(kp1.size), _p(kp2), C.c_int64(kp2.size), C.c_float(ratio_th),
                        _p(pairs), C.c_int64(cap))

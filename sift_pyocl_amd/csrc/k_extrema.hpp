@@ -1,0 +1,188 @@
+// k_extrema.hpp -- DoG extrema detection for the three detection scales in ONE pass over the six
+// blur planes, and sub-pixel refinement with compaction.
+//
+// Replaces combine x5 (algebra.cl:18-37), local_maxmin x3 (image.cl:119-213), interp_keypoint x3
+// (image.cl:235-369), compact x3 (algebra.cl:57-84) and the memsets between them.  DoG planes are
+// never stored: DoG[s] = blur[s] - blur[s+1] is recomputed where needed, which is the same single
+// IEEE subtraction the reference's combine() performs ((-1*b)+(1*a) == a-b exactly).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "siftmath.hpp"
+
+namespace siftk {
+
+struct BlurPlanes { const float *p[6]; };
+
+// 3x3x3 extremum test restated: v is kept as a maximum iff v > 0 and no sample of the 27 is
+// strictly greater, i.e. v >= max27 (image.cl:156-167); likewise for minima.  max27 is separable:
+// max over the 3 scales, then 3 columns (neighbour lanes), then 3 rows (rolling registers).
+// One wave scans a strip 62 columns wide (lanes 0 and 63 are halo) and ROWS_PER_STRIP rows high.
+#define SIFT_EXT_ROWS 32
+
+__device__ __forceinline__ float dog_at(const BlurPlanes &b, int s, size_t pos) { return b.p[s][pos] - b.p[s + 1][pos]; }
+
+__global__ __launch_bounds__(256) void extrema_kernel(BlurPlanes b, int W, int H, int border, double contrast,
+                                                      float edth, float4 *__restrict__ cand,
+                                                      int *__restrict__ counter, int capacity) {
+    const int lane = threadIdx.x & 63;
+    const int nx = (W - 2 * border + 61) / 62;
+    const int ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nx * ny) return;
+    const int sx = wid % nx, sy = wid / nx;
+    const int x = border + sx * 62 + lane - 1;
+    const int xc = min(max(x, 0), W - 1);
+    const bool col_ok = (lane >= 1) && (lane <= 62) && (x < W - border);
+    const int ya = border + sy * SIFT_EXT_ROWS;
+    const int yb = min(ya + SIFT_EXT_ROWS, H - border);
+
+    float hM[3][3], hm[3][3];   // [row slot][scale]: horizontal+scale max / min for rows y-2, y-1, y
+    float ctr[3] = {0.f, 0.f, 0.f}, ctr_next[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { hM[r][k] = 0.f; hm[r][k] = 0.f; }
+
+    for (int y = ya - 1; y <= yb; y++) {
+        const size_t pos = (size_t)y * W + xc;
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[k] = b.p[k][pos];
+        float d[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = v[k] - v[k + 1];
+        // shift rolling window
+#pragma unroll
+        for (int k = 0; k < 3; k++) { hM[0][k] = hM[1][k]; hM[1][k] = hM[2][k]; hm[0][k] = hm[1][k]; hm[1][k] = hm[2][k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float M = fmaxf(fmaxf(d[k], d[k + 1]), d[k + 2]);
+            const float m = fminf(fminf(d[k], d[k + 1]), d[k + 2]);
+            const float Ml = __shfl_up(M, 1), Mr = __shfl_down(M, 1);
+            const float ml = __shfl_up(m, 1), mr = __shfl_down(m, 1);
+            hM[2][k] = fmaxf(fmaxf(Ml, M), Mr);
+            hm[2][k] = fminf(fminf(ml, m), mr);
+            ctr_next[k] = d[k + 1];
+        }
+        // centre row is y-1; it is complete once rows y-2, y-1, y have been seen
+        if (y >= ya + 1 && col_ok) {
+            const int yc = y - 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float val = ctr[k];
+                if ((double)fabsf(val) > contrast) {
+                    const float M27 = fmaxf(fmaxf(hM[0][k], hM[1][k]), hM[2][k]);
+                    const float m27 = fminf(fminf(hm[0][k], hm[1][k]), hm[2][k]);
+                    const bool is_ext = (val > 0.0f) ? (val >= M27) : (val <= m27);
+                    if (is_ext) {
+                        const int s = k + 1;
+                        const size_t pc = (size_t)yc * W + x;
+                        // 2-D Hessian; "2.0" and "4.0" are double literals in image.cl:180-184
+                        const float up = dog_at(b, s, pc - W), dn = dog_at(b, s, pc + W);
+                        const float lf = dog_at(b, s, pc - 1), rt = dog_at(b, s, pc + 1);
+                        const float H00 = (float)(((double)up - 2.0 * (double)val) + (double)dn);
+                        const float H11 = (float)(((double)lf - 2.0 * (double)val) + (double)rt);
+                        const float dd = (dog_at(b, s, pc + W + 1) - dog_at(b, s, pc + W - 1)) -
+                                         (dog_at(b, s, pc - W + 1) - dog_at(b, s, pc - W - 1));
+                        const float H01 = (float)((double)dd / 4.0);
+                        const float det = H00 * H11 - H01 * H01;
+                        const float tr = H00 + H11;
+                        if (!(det < edth * tr * tr) && val != 0.0f) {
+                            const int old = atomicAdd(counter, 1);
+                            if (old < capacity) cand[old] = make_float4(val, (float)yc, (float)x, (float)s);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) ctr[k] = ctr_next[k];
+    }
+}
+
+// Sub-pixel refinement of every candidate + compaction of the survivors (image.cl:235-369,
+// algebra.cl:57-84).  One thread per candidate, grid-stride over the device-side count.
+// Output: (peak, row, col, sigma) and the integer detection scale (the reference keeps the
+// scale implicitly as the loop variable of plan.py:626).
+__global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H, const float4 *__restrict__ cand,
+                                                     const int *__restrict__ n_cand, int cand_capacity,
+                                                     float peak_thresh, float init_sigma,
+                                                     float4 *__restrict__ kp, int *__restrict__ kp_scale,
+                                                     int *__restrict__ n_kp, int kp_capacity) {
+    const int n = min(*n_cand, cand_capacity);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 k = cand[i];
+        int r = (int)k.y, c = (int)k.z;
+        const int scale = (int)k.w;
+        if (r == -1) continue;
+        const float *Pa = b.p[scale - 1], *Pb = b.p[scale], *Pc = b.p[scale + 1], *Pd = b.p[scale + 2];
+        // P = DoG[scale-1] = Pa-Pb, D = DoG[scale] = Pb-Pc, N = DoG[scale+1] = Pc-Pd
+        int newr = r, newc = c, moves = 5;
+        bool again = true;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, peak = 0.f;
+        while (again) {
+            r = newr; c = newc;
+            const size_t pos = (size_t)r * W + c;
+#define DOGP(o) (Pa[pos + (o)] - Pb[pos + (o)])
+#define DOGD(o) (Pb[pos + (o)] - Pc[pos + (o)])
+#define DOGN(o) (Pc[pos + (o)] - Pd[pos + (o)])
+            const float P0 = DOGP(0), D0 = DOGD(0), N0 = DOGN(0);
+            const float Dd = DOGD(W), Du = DOGD(-W), Dr = DOGD(1), Dl = DOGD(-1);
+            const float Pd_ = DOGP(W), Pu = DOGP(-W), Pr = DOGP(1), Pl = DOGP(-1);
+            const float Nd = DOGN(W), Nu = DOGN(-W), Nr = DOGN(1), Nl = DOGN(-1);
+            const float Ddr = DOGD(W + 1), Ddl = DOGD(W - 1), Dur = DOGD(-W + 1), Dul = DOGD(-W - 1);
+#undef DOGP
+#undef DOGD
+#undef DOGN
+            const float g0 = (N0 - P0) / 2.0f;
+            const float g1 = (Dd - Du) / 2.0f;
+            const float g2 = (Dr - Dl) / 2.0f;
+            const float H00 = P0 - 2.0f * D0 + N0;
+            const float H11 = Du - 2.0f * D0 + Dd;
+            const float H22 = Dl - 2.0f * D0 + Dr;
+            const float H01 = ((Nd - Nu) - (Pd_ - Pu)) / 4.0f;
+            const float H02 = ((Nr - Nl) - (Pr - Pl)) / 4.0f;
+            const float H12 = ((Ddr - Ddl) - (Dur - Dul)) / 4.0f;
+            const float H10 = H01, H20 = H02, H21 = H12;
+            const float det = -(H02 * H11 * H20) + H01 * H12 * H20 + H02 * H10 * H21
+                              - H00 * H12 * H21 - H01 * H10 * H22 + H00 * H11 * H22;
+            const float K00 = H11 * H22 - H12 * H21;
+            const float K01 = H02 * H21 - H01 * H22;
+            const float K02 = H01 * H12 - H02 * H11;
+            const float K10 = H12 * H20 - H10 * H22;
+            const float K11 = H00 * H22 - H02 * H20;
+            const float K12 = H02 * H10 - H00 * H12;
+            const float K20 = H10 * H21 - H11 * H20;
+            const float K21 = H01 * H20 - H00 * H21;
+            const float K22 = H00 * H11 - H01 * H10;
+            s0 = -(g0 * K00 + g1 * K01 + g2 * K02) / det;
+            s1 = -(g0 * K10 + g1 * K11 + g2 * K12) / det;
+            s2 = -(g0 * K20 + g1 * K21 + g2 * K22) / det;
+            peak = D0 + 0.5f * (s0 * g0 + s1 * g1 + s2 * g2);
+            if (s1 > 0.6f && newr < H - 3) newr++;
+            else if (s1 < -0.6f && newr > 3) newr--;
+            if (s2 > 0.6f && newc < W - 3) newc++;
+            else if (s2 < -0.6f && newc > 3) newc--;
+            if (moves > 0 && (newr != r || newc != c)) moves--;
+            else again = false;
+        }
+        if (fabsf(s0) <= 1.5f && fabsf(s1) <= 1.5f && fabsf(s2) <= 1.5f && fabsf(peak) >= peak_thresh) {
+            const float sig = init_sigma * siftmath::exp2f_(((float)scale + s0) / 3.0f);
+            const int slot = atomicAdd(n_kp, 1);
+            if (slot < kp_capacity) {
+                kp[slot] = make_float4(peak, (float)r + s1, (float)c + s2, sig);
+                kp_scale[slot] = scale;
+            }
+        }
+    }
+}
+
+// DoG plane (stage replay of algebra.cl:18-37 as called at plan.py:619-623)
+__global__ void dog_kernel(const float *__restrict__ a, const float *__restrict__ bnext, float *__restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = -1.0f * bnext[i] + 1.0f * a[i];
+}
+
+}  // namespace siftk

@@ -1,0 +1,353 @@
+// k_keypoint.hpp -- per-keypoint kernels: orientation assignment and the 128-D descriptor.
+//
+// Parity target is the reference's CPU variants (orientation_cpu.cl:41-174, keypoints_cpu.cl:36-161)
+// because those are what its "CPU devicetype" path runs.  Both accumulate float histograms in the
+// raster order of the sample window, and float addition is not associative, so bit-exact bins need
+// the same per-bin order.  Here one wavefront owns one keypoint: its 64 lanes evaluate 64 consecutive
+// samples of the raster scan at a time, and the histogram bins are owned by fixed lanes that add the
+// chunk's contributions in lane (= raster) order.
+//
+// Gradient magnitude / orientation (compute_gradient_orientation, image.cl:47-80) are not
+// materialised as full maps: they are evaluated from blur[scale] inside the window with the same
+// expressions, which yields the same values and saves 9 plane transfers per octave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "k_extrema.hpp"
+#include "siftmath.hpp"
+
+namespace siftk {
+
+struct KpRecord { float x, y, scale, angle; uint8_t desc[128]; };   // == siftmi_keypoint
+static_assert(sizeof(KpRecord) == 144, "record layout");
+
+// image.cl:58-77
+__device__ __forceinline__ void gradient_at(const float *__restrict__ I, int x, int y, int W, int H,
+                                            float &mag, float &ori) {
+    const size_t pos = (size_t)y * W + x;
+    float gx, gy;
+    if (x == 0) gx = 2.0f * (I[pos + 1] - I[pos]);
+    else if (x == W - 1) gx = 2.0f * (I[pos] - I[pos - 1]);
+    else gx = I[pos + 1] - I[pos - 1];
+    if (y == 0) gy = 2.0f * (I[pos] - I[pos + W]);
+    else if (y == H - 1) gy = 2.0f * (I[pos - W] - I[pos]);
+    else gy = I[pos - W] - I[pos + W];
+    mag = sqrtf(gx * gx + gy * gy);
+    ori = siftmath::atan2f_(-gy, gx);
+}
+
+// exact idx / d for 0 <= idx < 2^22, 1 <= d < 2^12 (inv = 1.0f / d)
+__device__ __forceinline__ int div_exact(int idx, int d, float inv, int &rem) {
+    int q = (int)((float)idx * inv);
+    rem = idx - q * d;
+    if (rem < 0) { q--; rem += d; }
+    else if (rem >= d) { q++; rem -= d; }
+    return q;
+}
+
+// device counters shared by the per-octave kernels
+struct Counters {
+    int n_cand;      // candidates of the current octave
+    int n_kp;        // refined keypoints of the current octave
+    int n_out;       // oriented keypoints, all octaves so far (index into the record list)
+    int oct_start;   // n_out at the start of the current octave
+    int overflow;    // set when a list hit its capacity
+    int pad[3];
+};
+
+__global__ void begin_octave_kernel(Counters *c) { c->n_cand = 0; c->n_kp = 0; c->oct_start = c->n_out; }
+__global__ void begin_image_kernel(Counters *c) { c->n_cand = 0; c->n_kp = 0; c->n_out = 0; c->oct_start = 0; c->overflow = 0; }
+__global__ void clamp_counts_kernel(Counters *c, int cand_cap, int kp_cap) {
+    if (c->n_cand > cand_cap) { c->n_cand = cand_cap; c->overflow = 1; }
+    if (c->n_kp > kp_cap) { c->n_kp = kp_cap; c->overflow = 1; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Orientation assignment: one wave per refined keypoint (orientation_cpu.cl:41-174).
+// Output goes straight to the image-wide oriented list (x, y, sigma*oct, angle) + detection scale.
+__global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, int H, int octsize, float ori_sigma,
+                                                          const float4 *__restrict__ kp,
+                                                          const int *__restrict__ kp_scale, Counters *cnt,
+                                                          int kp_capacity, float4 *__restrict__ okp,
+                                                          int *__restrict__ oaux, int out_capacity,
+                                                          int per_octave_capacity) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int n = min(cnt->n_kp, kp_capacity);
+    const int oct_start = cnt->oct_start;
+    for (int i = wave; i < n; i += nwaves) {
+        const float4 k = kp[i];          // (peak, row, col, sigma)
+        const int scale = kp_scale[i];
+        if (!(k.y >= 0.0f)) continue;
+        const float *I = b.p[scale];
+        const int row = (int)((double)k.y + 0.5), col = (int)((double)k.z + 0.5);
+        const float sigma = ori_sigma * k.w;
+        const int radius = (int)((double)sigma * 3.0);
+        const int rmin = max(0, row - radius), cmin = max(0, col - radius);
+        const int rmax = min(row + radius, H - 2), cmax = min(col + radius, W - 2);
+        const float lim = (float)(radius * radius) + 0.5f;
+        const float two_s2 = 2.0f * sigma * sigma;
+        const int wc = cmax - cmin + 1, hr = rmax - rmin + 1;
+        const int total = (wc > 0 && hr > 0) ? wc * hr : 0;
+        const float inv_wc = 1.0f / (float)max(wc, 1);
+        float h = 0.0f;                  // lane b < 36 owns hist[b]
+        for (int base = 0; base < total; base += 64) {
+            const int idx = base + lane;
+            bool valid = idx < total;
+            int bin = -1;
+            float val = 0.0f;
+            if (valid) {
+                int rem;
+                const int q = div_exact(idx, wc, inv_wc, rem);
+                const int r = rmin + q, c = cmin + rem;
+                float gval, a;
+                gradient_at(I, c, r, W, H, gval, a);
+                float dif = (float)r - k.y;
+                float distsq = dif * dif;
+                dif = (float)c - k.z;
+                distsq = distsq + dif * dif;
+                valid = (gval > 0.0f) && (distsq < lim);
+                if (valid) {
+                    bin = (int)(36.0f * (a + SM_PI_F + 0.001f) / (2.0f * SM_PI_F));
+                    valid = (bin >= 0) && (bin <= 36);
+                    bin = min(bin, 35);
+                    val = siftmath::expf_(-distsq / two_s2) * gval;
+                }
+            }
+            uint64_t mask = __ballot(valid);
+            while (mask) {               // raster order == ascending lane
+                const int l = __ffsll((unsigned long long)mask) - 1;
+                mask &= mask - 1;
+                const int sb = __builtin_amdgcn_readlane(bin, l);
+                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), l));
+                if (lane == sb) h = h + sv;
+            }
+        }
+        // six passes of circular [1 1 1]/3 smoothing; hist[35] sees the already updated hist[0];
+        // the division is by the double literal 3.0 (orientation_cpu.cl:101-109)
+        const int lp = (lane == 0) ? 35 : lane - 1, ln = (lane >= 35) ? 0 : lane + 1;
+#pragma unroll 1
+        for (int pass = 0; pass < 6; pass++) {
+            const float prev = __shfl(h, lp), nxt = __shfl(h, ln);
+            float nh = (float)((double)((prev + h) + nxt) / 3.0);
+            const float nh0 = __shfl(nh, 0);
+            if (lane == 35) nh = (float)((double)((prev + h) + nh0) / 3.0);
+            h = (lane < 36) ? nh : 0.0f;
+        }
+        float mx = (lane < 36) ? h : 0.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float maxval = fmaxf(mx, 0.0f);
+        const uint64_t eq = __ballot(lane < 36 && h == maxval);
+        const int argmax = (maxval > 0.0f && eq) ? (__ffsll((unsigned long long)eq) - 1) : 0;
+        const float hp = __shfl(h, argmax == 0 ? 35 : argmax - 1);
+        const float hn = __shfl(h, argmax == 35 ? 0 : argmax + 1);
+        const float interp = 0.5f * (hp - hn) / (hp - 2.0f * maxval + hn);
+        const float angle = 2.0f * SM_PI_F * ((float)argmax + 0.5f + interp) / 36.0f - SM_PI_F;
+        // further peaks >= 80 % of the maximum (orientation_cpu.cl:153-172)
+        const float hpp = __shfl(h, lp), hnn = __shfl(h, ln);
+        bool extra = (lane < 36) && h > hpp && h > hnn && h >= 0.8f * maxval && lane != argmax;
+        float a2 = 0.0f;
+        if (extra) {
+            const float it = 0.5f * (hpp - hnn) / (hpp - 2.0f * h + hnn);
+            a2 = (float)((double)(2.0f * SM_PI_F * ((float)lane + 0.5f + it)) / 36.0 - (double)SM_PI_F);
+            extra = (a2 >= -SM_PI_F) && (a2 <= SM_PI_F);
+        }
+        const uint64_t emask = __ballot(extra);
+        const float ox = k.z * (float)octsize, oy = k.y * (float)octsize, os = k.w * (float)octsize;
+        const float sum4 = ((ox + oy) + os) + angle;
+        const int nmain = (sum4 == sum4) ? 1 : 0;     // host NaN sieve of plan.py:545-550, done here
+        const int nextra = __popcll((unsigned long long)emask);
+        int slot0 = 0;
+        if (lane == 0 && nmain + nextra > 0) slot0 = atomicAdd(&cnt->n_out, nmain + nextra);
+        slot0 = __shfl(slot0, 0);
+        if (lane == 0 && nmain) {
+            if (slot0 < out_capacity && slot0 - oct_start < per_octave_capacity) {
+                okp[slot0] = make_float4(ox, oy, os, angle);
+                oaux[slot0] = scale;
+            } else cnt->overflow = 1;
+        }
+        if (extra) {
+            const int slot = slot0 + nmain + __popcll((unsigned long long)(emask & ((1ull << lane) - 1ull)));
+            if (slot < out_capacity && slot - oct_start < per_octave_capacity) {
+                okp[slot] = make_float4(ox, oy, os, a2);
+                oaux[slot] = scale;
+            } else cnt->overflow = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Descriptor: one single-wave workgroup per oriented keypoint (keypoints_cpu.cl:36-161).
+// LDS holds a 64 x 128 contribution table: row = sample lane of the current chunk, column = bin.
+// A sample touches at most 8 distinct bins, so each lane writes <= 8 cells; lane l then owns bins
+// 2l, 2l+1 and adds the table rows in ascending (raster) order; the other cells are exact +0.0f.
+__global__ __launch_bounds__(64) void descriptor_kernel(BlurPlanes b, int W, int H, int octsize,
+                                                        const float4 *__restrict__ okp,
+                                                        const int *__restrict__ oaux, const Counters *cnt,
+                                                        int range_start, int range_end,  // used when cnt == nullptr
+                                                        int out_capacity, KpRecord *__restrict__ records) {
+    __shared__ float T[64 * 128];
+    const int lane = threadIdx.x;
+    int start = range_start, end = range_end;
+    if (cnt) { start = cnt->oct_start; end = min(cnt->n_out, out_capacity); }
+    for (int k = lane; k < 64 * 128; k += 64) T[k] = 0.0f;
+    __syncthreads();
+    for (int i = start + blockIdx.x; i < end; i += gridDim.x) {
+        const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
+        const int scale = oaux[i];
+        KpRecord *rec = records + i;
+        if (!(kq.y >= 0.0f)) {
+            if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
+            reinterpret_cast<uint16_t *>(rec->desc)[lane] = 0;
+            continue;
+        }
+        const float *I = b.p[scale];
+        const float foct = (float)octsize;
+        const float row = kq.y / foct, col = kq.x / foct, angle = kq.w;
+        const int irow = (int)(row + 0.5f), icol = (int)(col + 0.5f);
+        float sine, cosine;
+        siftmath::sincosf_(angle, &sine, &cosine);
+        const float spacing = kq.z / foct * 3.0f;
+        const int iradius = (int)((1.414f * spacing * 2.5f) + 0.5f);
+        const float drow = row - (float)irow, dcol = col - (float)icol;
+        const int S = 2 * iradius + 1;
+        const int total = S * S;
+        const float inv_S = 1.0f / (float)S;
+        float acc0 = 0.0f, acc1 = 0.0f;  // bins 2*lane, 2*lane+1
+        for (int base = 0; base < total; base += 64) {
+            const int idx = base + lane;
+            bool inside = false;
+            float rx = 0.f, cx = 0.f;
+            int yy = 0, xx = 0;
+            if (idx < total) {
+                int rem;
+                const int q = div_exact(idx, S, inv_S, rem);
+                const int ii = q - iradius, jj = rem - iradius;
+                rx = ((cosine * (float)ii - sine * (float)jj) - drow) / spacing + 1.5f;
+                cx = ((sine * (float)ii + cosine * (float)jj) - dcol) / spacing + 1.5f;
+                yy = irow + ii; xx = icol + jj;
+                inside = rx > -1.0f && rx < 4.0f && cx > -1.0f && cx < 4.0f && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            }
+            if (__ballot(inside) == 0) continue;
+            bool contributes = false;
+            int cell[8];
+            if (inside) {
+                float g, o;
+                gradient_at(I, xx, yy, W, H, g, o);
+                const float er = rx - 1.5f, ec = cx - 1.5f;
+                const float mag = g * siftmath::expf_(-0.125f * (er * er + ec * ec));
+                o = o - angle;
+                while (o > 2.0f * SM_PI_F) o -= 2.0f * SM_PI_F;
+                while (o < 0.0f) o += 2.0f * SM_PI_F;
+                const float oval = 4.0f * o * SM_1_PI_F;
+                const int ri = (int)((rx >= 0.0f) ? rx : rx - 1.0f);
+                const int ci = (int)((cx >= 0.0f) ? cx : cx - 1.0f);
+                const int oi = (int)((oval >= 0.0f) ? oval : oval - 1.0f);
+                const float rf = rx - (float)ri, cf = cx - (float)ci, of = oval - (float)oi;
+                contributes = ri >= -1 && ri < 4 && oi >= 0 && oi <= 8 && rf >= 0.0f && rf <= 1.0f;
+                if (contributes) {
+#pragma unroll
+                    for (int a = 0; a < 2; a++) {
+                        const int rb = ri + a;
+                        const float rw = mag * (a == 0 ? 1.0f - rf : rf);
+#pragma unroll
+                        for (int bb = 0; bb < 2; bb++) {
+                            const int cb = ci + bb;
+                            const float cw = rw * (bb == 0 ? 1.0f - cf : cf);
+                            const bool ok = rb >= 0 && rb < 4 && cb >= 0 && cb < 4;
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                int ob = oi + e;
+                                // oi == 8 only for oval == 8.0f exactly (ori == 2*pi_f), where of == 0:
+                                // e=0 adds cw*1 to bin 0, e=1 adds cw*0 == +0 (no effect) -> skipped.
+                                const bool dup = (e == 1 && oi == 8);
+                                if (ob >= 8) ob = 0;
+                                const int n8 = a * 4 + bb * 2 + e;
+                                if (ok && !dup) {
+                                    cell[n8] = lane * 128 + (rb * 4 + cb) * 8 + ob;
+                                    T[cell[n8]] = cw * (e == 0 ? 1.0f - of : of);
+                                } else cell[n8] = -1;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            uint64_t mask = __ballot(contributes);
+            while (mask) {
+                const int l = __ffsll((unsigned long long)mask) - 1;
+                mask &= mask - 1;
+                const float2 v = *reinterpret_cast<const float2 *>(&T[l * 128 + 2 * lane]);
+                acc0 = acc0 + v.x;
+                acc1 = acc1 + v.y;
+            }
+            __syncthreads();
+            if (contributes) {
+#pragma unroll
+                for (int n8 = 0; n8 < 8; n8++) if (cell[n8] >= 0) T[cell[n8]] = 0.0f;
+            }
+            __syncthreads();
+        }
+        // ---- normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160).
+        // The reference sums the 128 squares sequentially in index order: reproduce that order.
+        float *V = T;                    // row 0 of the table is free again
+        *reinterpret_cast<float2 *>(&V[2 * lane]) = make_float2(acc0, acc1);
+        __syncthreads();
+        float norm = 0.0f;
+#pragma unroll 8
+        for (int k2 = 0; k2 < 128; k2++) { const float t = V[k2]; norm = norm + t * t; }
+        norm = 1.0f / sqrtf(norm);       // rsqrt
+        acc0 = acc0 * norm; acc1 = acc1 * norm;
+        const bool ch = (acc0 > 0.2f) || (acc1 > 0.2f);
+        if (acc0 > 0.2f) acc0 = 0.2f;
+        if (acc1 > 0.2f) acc1 = 0.2f;
+        __syncthreads();
+        *reinterpret_cast<float2 *>(&V[2 * lane]) = make_float2(acc0, acc1);
+        __syncthreads();
+        if (__ballot(ch)) {
+            float n2 = 0.0f;
+#pragma unroll 8
+            for (int k2 = 0; k2 < 128; k2++) { const float t = V[k2]; n2 = n2 + t * t; }
+            n2 = 1.0f / sqrtf(n2);
+            acc0 = acc0 * n2; acc1 = acc1 * n2;
+        }
+        __syncthreads();
+        *reinterpret_cast<float2 *>(&V[2 * lane]) = make_float2(0.f, 0.f);   // table back to all zero
+        // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see oracle note)
+        const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
+        const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
+        const uint32_t b0 = (uint32_t)min(255, i0) & 0xffu, b1 = (uint32_t)min(255, i1) & 0xffu;
+        if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
+        reinterpret_cast<uint16_t *>(rec->desc)[lane] = (uint16_t)(b0 | (b1 << 8));
+        __syncthreads();
+    }
+}
+
+// full-map gradient (stage replay of image.cl:47-80)
+__global__ void gradient_kernel(const float *__restrict__ img, float *__restrict__ grad, float *__restrict__ ori, int W, int H) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    float g, o;
+    gradient_at(img, x, y, W, H, g, o);
+    grad[(size_t)y * W + x] = g;
+    ori[(size_t)y * W + x] = o;
+}
+
+// elementwise siftmath (test hook)
+__global__ void math_kernel(int fn, const float *__restrict__ a, const float *__restrict__ bb, float *__restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float s, c;
+        switch (fn) {
+            case 0: out[i] = siftmath::expf_(a[i]); break;
+            case 1: out[i] = siftmath::exp2f_(a[i]); break;
+            case 2: siftmath::sincosf_(a[i], &s, &c); out[i] = s; break;
+            case 3: siftmath::sincosf_(a[i], &s, &c); out[i] = c; break;
+            default: out[i] = siftmath::atan2f_(a[i], bb[i]); break;
+        }
+    }
+}
+
+}  // namespace siftk

@@ -1,0 +1,885 @@
+// siftmi.hip -- host side of libsiftmi.so: the C ABI of include/siftmi.h over the gfx950 kernels.
+//
+// One plan = one HIP device + one stream + every buffer pre-allocated (as SiftPlan.__init__ does,
+// sift-src/plan.py:117-201,268-306).  keypoints() enqueues the whole pyramid / detection /
+// description chain without reading anything back and synchronises once at the end; the
+// reference's host loop (plan.py:596-756) reads a 4-byte counter back >= 18 times per octave.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/siftmi.h"
+#include "k_extrema.hpp"
+#include "k_keypoint.hpp"
+#include "k_match.hpp"
+#include "k_pyramid.hpp"
+#include "siftmath.hpp"
+
+using namespace siftk;
+
+static_assert(sizeof(siftmi_keypoint) == 144, "siftmi_keypoint must be 144 bytes");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? SIFTMI_ENOMEM : SIFTMI_EDEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                \
+    } while (0)
+
+// ---- Gaussian taps on the host: gaussian.cl:56-140 run as one work-group of nextpower(size)
+// items (plan.py:321-330); LDS tree sum restated serially in the same association order.
+int nextpower(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+int gaussian_taps(float sigma, int size, float *out) {
+    if (size < 1 || size > 1024) return fail(SIFTMI_EINVAL, "gaussian size %d out of range", size);
+    int P = nextpower(size);
+    if (P < 2) P = 2;
+    std::vector<float> g((size_t)P, 0.0f), sum((size_t)P, 0.0f);
+    const float norm = sqrtf(2.0f * SM_PI_F);
+    for (int i = 0; i < size; i++) {
+        const float x = ((float)i - ((float)size - 1.0f) / 2.0f) / sigma;
+        const float y = siftmath::expf_(-x * x / 2.0f);
+        g[(size_t)i] = y / sigma / norm;
+        sum[(size_t)i] = g[(size_t)i];
+    }
+    for (int stride = 512; stride >= 2; stride >>= 1)
+        if (size > stride)
+            for (int i = 0; i < stride && i + stride < P; i++) sum[(size_t)i] += sum[(size_t)(i + stride)];
+    sum[0] += sum[1];
+    for (int i = 0; i < size; i++) out[i] = g[(size_t)i] / sum[0];
+    return SIFTMI_OK;
+}
+
+int kernel_size(double sigma) {   // utils.py:54-64 with odd=True, cutoff=4
+    int size = (int)std::ceil(2.0 * 4.0 * sigma + 1.0);
+    if (size % 2 == 0) size += 1;
+    return size;
+}
+
+struct Taps { int n = 0; float t[64] = {0}; float *dev = nullptr; };
+
+struct Event { std::string label; hipEvent_t a = nullptr, b = nullptr; bool is_blur = false; double pixels = 0; };
+
+size_t dtype_size(int dt) {
+    switch (dt) {
+        case SIFTMI_F32: return 4; case SIFTMI_U8: return 1; case SIFTMI_U16: return 2; case SIFTMI_U32: return 4;
+        case SIFTMI_U64: return 8; case SIFTMI_I32: return 4; case SIFTMI_I64: return 8; case SIFTMI_F64: return 8;
+        case SIFTMI_RGB8: return 3;
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct siftmi_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int H = 0, W = 0, dtype = 0;
+    siftmi_params par{};
+    int profile = 0;
+    int n_oct = 0;
+    std::vector<int> ow, oh;
+    int64_t kpsize = 0;
+    int64_t bytes = 0;
+    float *blur[6] = {nullptr};
+    float *tmp = nullptr;         // generic blur only
+    void *raw = nullptr;          // host-input staging (any dtype)
+    float *conv = nullptr;        // converted f32 input when dtype != f32
+    uint32_t *mm = nullptr;
+    Counters *cnt = nullptr;
+    float4 *cand = nullptr;
+    float4 *kp = nullptr;
+    int *kp_scale = nullptr;
+    float4 *okp = nullptr;
+    int *oaux = nullptr;
+    KpRecord *records = nullptr;
+    Taps taps[6];                 // [0..4] per-octave schedule, [5] initial blur
+    bool have_init = false;
+    std::vector<Event> events;
+    size_t n_events = 0;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    float last_min = 0, last_max = 0;
+    std::vector<void *> allocs;
+
+    template <class T> int alloc(T **p, size_t nbytes) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, nbytes ? nbytes : 16);
+        if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu bytes): %s", nbytes, hipGetErrorString(e));
+        allocs.push_back(q);
+        bytes += (int64_t)nbytes;
+        *p = (T *)q;
+        return SIFTMI_OK;
+    }
+};
+
+namespace {
+
+int compute_schedule(siftmi_plan *p) {
+    // plan.py:534-539 (initial blur) and plan.py:602-618 (per-octave increments)
+    const double init_sigma = p->par.init_sigma;
+    p->have_init = false;
+    if (init_sigma > 0.5) {   // par.DoubleImSize == 0 -> curSigma = 0.5
+        const double s = std::sqrt(init_sigma * init_sigma - 0.25);
+        p->taps[5].n = kernel_size(s);
+        if (p->taps[5].n > 64) return fail(SIFTMI_EINVAL, "init_sigma %g needs %d taps (> 64)", init_sigma, p->taps[5].n);
+        int rc = gaussian_taps((float)s, p->taps[5].n, p->taps[5].t);
+        if (rc) return rc;
+        p->have_init = true;
+    }
+    const double ratio = std::pow(2.0, 1.0 / 3.0);   // SiftPlan.sigmaRatio, par.Scales == 3
+    double prev = init_sigma;
+    for (int s = 0; s < 5; s++) {
+        const double inc = prev * std::sqrt(ratio * ratio - 1.0);
+        p->taps[s].n = kernel_size(inc);
+        if (p->taps[s].n > 64) return fail(SIFTMI_EINVAL, "sigma %g needs %d taps (> 64)", inc, p->taps[s].n);
+        int rc = gaussian_taps((float)inc, p->taps[s].n, p->taps[s].t);
+        if (rc) return rc;
+        prev *= ratio;
+    }
+    for (int s = 0; s < 6; s++) {
+        if (!p->taps[s].dev) { int rc = p->alloc(&p->taps[s].dev, 64 * sizeof(float)); if (rc) return rc; }
+        HIPCHK(hipMemcpy(p->taps[s].dev, p->taps[s].t, 64 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return SIFTMI_OK;
+}
+
+template <int N, bool NORM>
+void launch_blur_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+    using G = BlurGeom<N>;
+    TapsArg<N> ta;
+    for (int i = 0; i < N; i++) ta.t[i] = taps[i];
+    dim3 grid((unsigned)((W + G::TX - 1) / G::TX), (unsigned)((H + G::TY - 1) / G::TY));
+    hipLaunchKernelGGL((blur_hv_kernel<N, NORM>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
+}
+
+// returns false when no tiled instantiation exists for this tap count
+template <bool NORM>
+bool launch_blur_tiled(hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
+    switch (t.n) {
+        case 11: launch_blur_t<11, NORM>(st, in, out, W, H, t.t, mm); return true;
+        case 15: launch_blur_t<15, NORM>(st, in, out, W, H, t.t, mm); return true;
+        case 17: launch_blur_t<17, NORM>(st, in, out, W, H, t.t, mm); return true;
+        case 21: launch_blur_t<21, NORM>(st, in, out, W, H, t.t, mm); return true;
+        case 27: launch_blur_t<27, NORM>(st, in, out, W, H, t.t, mm); return true;
+        default: return false;
+    }
+}
+
+void launch_blur_generic(hipStream_t st, const float *in, float *out, float *tmp, int W, int H, const Taps &t,
+                         const uint32_t *mm, bool norm) {
+    dim3 grid((unsigned)((W + 255) / 256), (unsigned)H);
+    hipLaunchKernelGGL(blur_generic_pass, grid, dim3(256), 0, st, in, tmp, W, H, t.dev, t.n, 0, mm, norm ? 1 : 0);
+    hipLaunchKernelGGL(blur_generic_pass, grid, dim3(256), 0, st, (const float *)tmp, out, W, H, t.dev, t.n, 1, mm, 0);
+}
+
+void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm) {
+    bool ok = norm ? launch_blur_tiled<true>(p->stream, in, out, W, H, t, p->mm)
+                   : launch_blur_tiled<false>(p->stream, in, out, W, H, t, p->mm);
+    if (!ok) launch_blur_generic(p->stream, in, out, p->tmp, W, H, t, p->mm, norm);
+}
+
+struct Scope {   // optional hipEvent bracket around one launch
+    siftmi_plan *p; size_t idx = (size_t)-1;
+    Scope(siftmi_plan *pl, const char *label, bool is_blur = false, double pixels = 0) : p(pl) {
+        if (!p->profile) return;
+        if (p->n_events == p->events.size()) {
+            Event e;
+            hipEventCreate(&e.a); hipEventCreate(&e.b);
+            p->events.push_back(e);
+        }
+        idx = p->n_events++;
+        Event &e = p->events[idx];
+        e.label = label; e.is_blur = is_blur; e.pixels = pixels;
+        hipEventRecord(e.a, p->stream);
+    }
+    ~Scope() { if (idx != (size_t)-1) hipEventRecord(p->events[idx].b, p->stream); }
+};
+
+int grid_for(int64_t n, int block, int max_blocks) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+double contrast_threshold(const siftmi_params &par) { return 0.8 * (double)par.peak_thresh; }   // image.cl:152
+
+void launch_detect_octave(siftmi_plan *p, int oct) {
+    const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
+    const int octsize = 1 << oct;
+    char lab[96];
+    BlurPlanes bp;
+    for (int s = 0; s < 6; s++) bp.p[s] = p->blur[s];
+    const int border = p->par.border_dist;
+    const int kcap = (int)p->kpsize;
+    if (W > 2 * border && H > 2 * border) {
+        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
+        const int blocks = (nx * ny + 3) / 4;
+        const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
+        snprintf(lab, sizeof lab, "local_maxmin %d", oct);
+        Scope sc(p, lab);
+        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, p->stream, bp, W, H, border,
+                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand, kcap);
+    }
+    {
+        snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
+        Scope sc(p, lab);
+        hipLaunchKernelGGL(clamp_counts_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt, kcap, kcap);
+        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, p->stream, bp, W, H, (const float4 *)p->cand,
+                           (const int *)&p->cnt->n_cand, kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
+                           p->kp_scale, &p->cnt->n_kp, kcap);
+        hipLaunchKernelGGL(clamp_counts_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt, kcap, kcap);
+    }
+    {
+        snprintf(lab, sizeof lab, "orientation_assignment %d", oct);
+        Scope sc(p, lab);
+        hipLaunchKernelGGL(orientation_kernel, dim3(1024), dim3(256), 0, p->stream, bp, W, H, octsize, p->par.ori_sigma,
+                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, kcap, p->okp, p->oaux, kcap, kcap);
+    }
+    {
+        snprintf(lab, sizeof lab, "descriptors %d", oct);
+        Scope sc(p, lab);
+        hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(64), 0, p->stream, bp, W, H, octsize,
+                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, 0, 0, kcap, p->records);
+    }
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+const char *siftmi_last_error(void) { return g_err.c_str(); }
+const char *siftmi_version(void) { return "sift_pyocl_amd 0.1 (gfx950)"; }
+
+int siftmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int siftmi_device_name(int device_id, char *buf, int64_t buflen) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    snprintf(buf, (size_t)buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id,
+                       const siftmi_params *params, int32_t profile, siftmi_plan **out) {
+    if (!out || !params) return fail(SIFTMI_EINVAL, "null argument");
+    *out = nullptr;
+    if (height < 1 || width < 1) return fail(SIFTMI_EINVAL, "bad shape %dx%d", height, width);
+    if ((int64_t)height * width > (int64_t)1 << 31) return fail(SIFTMI_EINVAL, "image too large");
+    if (dtype_size(in_dtype) == 0) return fail(SIFTMI_EINVAL, "invalid input format (%d)", in_dtype);
+    if (params->pix_per_kp < 1) return fail(SIFTMI_EINVAL, "pix_per_kp must be >= 1");
+    if (params->border_dist < 1) return fail(SIFTMI_EINVAL, "border_dist must be >= 1");
+    int ndev = siftmi_device_count();
+    if (ndev < 1) return fail(SIFTMI_EDEVICE, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(SIFTMI_EINVAL, "device %d out of range (%d devices)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    siftmi_plan *p = new (std::nothrow) siftmi_plan();
+    if (!p) return fail(SIFTMI_ENOMEM, "host allocation failed");
+    p->device = device_id; p->H = height; p->W = width; p->dtype = in_dtype; p->par = *params; p->profile = profile;
+    // octave shapes, plan.py:213-224
+    {
+        int h = height, w = width;
+        std::vector<int> hh{h}, ww{w};
+        while ((h < w ? h : w) > 2 * params->border_dist + 2) { h /= 2; w /= 2; hh.push_back(h); ww.push_back(w); }
+        hh.pop_back(); ww.pop_back();
+        p->oh = hh; p->ow = ww;
+        p->n_oct = (int)hh.size();
+        if (params->octave_max > 0 && params->octave_max < p->n_oct) p->n_oct = params->octave_max;
+    }
+    const size_t N = (size_t)height * width;
+    p->kpsize = (int64_t)(N / (size_t)params->pix_per_kp);   // plan.py:243
+    if (p->kpsize < 1) p->kpsize = 1;
+    int rc = SIFTMI_OK;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete p; return fail(SIFTMI_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    for (int s = 0; s < 6 && !rc; s++) rc = p->alloc(&p->blur[s], N * sizeof(float));
+    if (!rc) rc = p->alloc(&p->tmp, N * sizeof(float));
+    if (!rc) rc = p->alloc(&p->raw, N * (dtype_size(in_dtype) > 4 ? dtype_size(in_dtype) : 4));
+    if (!rc && in_dtype != SIFTMI_F32) rc = p->alloc(&p->conv, N * sizeof(float));
+    if (!rc) rc = p->alloc(&p->mm, 2 * sizeof(uint32_t));
+    if (!rc) rc = p->alloc(&p->cnt, sizeof(Counters));
+    if (!rc) rc = p->alloc(&p->cand, (size_t)p->kpsize * sizeof(float4));
+    if (!rc) rc = p->alloc(&p->kp, (size_t)p->kpsize * sizeof(float4));
+    if (!rc) rc = p->alloc(&p->kp_scale, (size_t)p->kpsize * sizeof(int));
+    if (!rc) rc = p->alloc(&p->okp, (size_t)p->kpsize * sizeof(float4));
+    if (!rc) rc = p->alloc(&p->oaux, (size_t)p->kpsize * sizeof(int));
+    if (!rc) rc = p->alloc(&p->records, (size_t)p->kpsize * sizeof(KpRecord));
+    if (!rc) rc = compute_schedule(p);
+    if (!rc && hipMemset(p->cnt, 0, sizeof(Counters)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipMemset failed");
+    if (!rc) { hipEventCreate(&p->ev_first); hipEventCreate(&p->ev_last); }
+    if (rc) { std::string keep = g_err; siftmi_plan_destroy(p); g_err = keep; return rc; }
+    *out = p;
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_destroy(siftmi_plan *p) {
+    if (!p) return SIFTMI_OK;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    for (void *q : p->allocs) hipFree(q);
+    for (Event &e : p->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (p->ev_first) hipEventDestroy(p->ev_first);
+    if (p->ev_last) hipEventDestroy(p->ev_last);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_info(const siftmi_plan *p, int32_t *n_octaves, int64_t *kpsize, int64_t *bytes_allocated) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (n_octaves) *n_octaves = p->n_oct;
+    if (kpsize) *kpsize = p->kpsize;
+    if (bytes_allocated) *bytes_allocated = p->bytes;
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_set_params(siftmi_plan *p, const siftmi_params *params) {
+    if (!p || !params) return fail(SIFTMI_EINVAL, "null argument");
+    if (params->pix_per_kp != p->par.pix_per_kp || params->border_dist != p->par.border_dist ||
+        params->octave_max != p->par.octave_max)
+        return fail(SIFTMI_EINVAL, "pix_per_kp / border_dist / octave_max are fixed at plan creation");
+    HIPCHK(hipSetDevice(p->device));
+    const bool resched = params->init_sigma != p->par.init_sigma;
+    p->par = *params;
+    return resched ? compute_schedule(p) : SIFTMI_OK;
+}
+
+int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t image_is_device, siftmi_keypoint *out,
+                          int32_t out_is_device, int64_t capacity, int64_t *n_out, int32_t *overflow) {
+    if (!p || !image || !n_out) return fail(SIFTMI_EINVAL, "null argument");
+    if (capacity > 0 && !out) return fail(SIFTMI_EINVAL, "null output with capacity > 0");
+    if (image_dtype != p->dtype && image_dtype != SIFTMI_F32)
+        return fail(SIFTMI_EINVAL, "image dtype %d is neither the plan's (%d) nor float32", image_dtype, p->dtype);
+    HIPCHK(hipSetDevice(p->device));
+    *n_out = 0;
+    if (overflow) *overflow = 0;
+    const size_t N = (size_t)p->H * p->W;
+    const void *src = image;
+    if (image_is_device) {
+        HIPCHK(hipDeviceSynchronize());   // order after the caller's work on other streams
+    } else {
+        HIPCHK(hipMemcpyAsync(p->raw, image, N * dtype_size(image_dtype), hipMemcpyHostToDevice, p->stream));
+        src = p->raw;
+    }
+    p->n_events = 0;
+    if (p->profile) hipEventRecord(p->ev_first, p->stream);
+    hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt);
+    const float *f32src = (const float *)src;
+    if (image_dtype != SIFTMI_F32) {
+        Scope sc(p, "convert -> float");
+        const int g = grid_for((int64_t)N, 256, 4096);
+        switch (image_dtype) {
+            case SIFTMI_U8: hipLaunchKernelGGL(convert_kernel<uint8_t>, dim3(g), dim3(256), 0, p->stream, (const uint8_t *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_U16: hipLaunchKernelGGL(convert_kernel<uint16_t>, dim3(g), dim3(256), 0, p->stream, (const uint16_t *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_U32: hipLaunchKernelGGL(convert_kernel<uint32_t>, dim3(g), dim3(256), 0, p->stream, (const uint32_t *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_U64: hipLaunchKernelGGL(convert_kernel<uint64_t>, dim3(g), dim3(256), 0, p->stream, (const uint64_t *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_I32: hipLaunchKernelGGL(convert_kernel<int32_t>, dim3(g), dim3(256), 0, p->stream, (const int32_t *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_I64: hipLaunchKernelGGL(convert_kernel<int64_t>, dim3(g), dim3(256), 0, p->stream, (const int64_t *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_F64: hipLaunchKernelGGL(convert_kernel<double>, dim3(g), dim3(256), 0, p->stream, (const double *)src, p->conv, (int64_t)N); break;
+            case SIFTMI_RGB8: hipLaunchKernelGGL(convert_rgb_kernel, dim3(g), dim3(256), 0, p->stream, (const uint8_t *)src, p->conv, (int64_t)N); break;
+            default: return fail(SIFTMI_EINVAL, "invalid input format");
+        }
+        f32src = p->conv;
+    }
+    {
+        Scope sc(p, "max_min");
+        hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, p->stream, p->mm);
+        hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, 2048)), dim3(256), 0, p->stream, f32src,
+                           (int64_t)N, p->mm);
+    }
+    if (p->have_init) {
+        Scope sc(p, "normalize + initial blur", true, (double)N);
+        launch_blur(p, f32src, p->blur[0], p->W, p->H, p->taps[5], true);
+    } else {
+        Scope sc(p, "normalize");
+        hipLaunchKernelGGL(normalize_kernel, dim3(grid_for((int64_t)N, 256, 4096)), dim3(256), 0, p->stream, f32src,
+                           p->blur[0], (int64_t)N, (const uint32_t *)p->mm);
+    }
+    char lab[96];
+    for (int oct = 0; oct < p->n_oct; oct++) {
+        const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
+        hipLaunchKernelGGL(begin_octave_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt);
+        for (int s = 0; s < 5; s++) {
+            snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
+            Scope sc(p, lab, true, (double)W * H);
+            launch_blur(p, p->blur[s], p->blur[s + 1], W, H, p->taps[s], false);
+        }
+        launch_detect_octave(p, oct);
+        if (oct < p->n_oct - 1) {
+            const int SW = p->ow[(size_t)oct + 1], SH = p->oh[(size_t)oct + 1];
+            snprintf(lab, sizeof lab, "shrink %d", oct);
+            Scope sc(p, lab);
+            hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, p->stream,
+                               (const float *)p->blur[3], p->blur[0], W, SW, SH);
+        }
+    }
+    if (p->profile) hipEventRecord(p->ev_last, p->stream);
+    Counters hc;
+    HIPCHK(hipMemcpyAsync(&hc, p->cnt, sizeof hc, hipMemcpyDeviceToHost, p->stream));
+    uint32_t hmm[2];
+    HIPCHK(hipMemcpyAsync(hmm, p->mm, sizeof hmm, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    {
+        auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
+        p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
+    }
+    int64_t n = hc.n_out;
+    int ovf = hc.overflow;
+    if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
+    int rc = SIFTMI_OK;
+    if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "output capacity too small; result truncated"; }
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(out, p->records, (size_t)n * sizeof(KpRecord),
+                              out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+    }
+    *n_out = n;
+    if (overflow) *overflow = ovf;
+    return rc;
+}
+
+int siftmi_plan_get_minmax(const siftmi_plan *p, float *mn, float *mx) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (mn) *mn = p->last_min;
+    if (mx) *mx = p->last_max;
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_profile(const siftmi_plan *p, char *buf, int64_t buflen) {
+    if (!p || !buf || buflen < 1) return fail(SIFTMI_EINVAL, "bad argument");
+    std::string s;
+    char line[160];
+    for (size_t i = 0; i < p->n_events; i++) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, p->events[i].a, p->events[i].b);
+        snprintf(line, sizeof line, "%s\t%.6f\n", p->events[i].label.c_str(), ms);
+        s += line;
+    }
+    snprintf(buf, (size_t)buflen, "%s", s.c_str());
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_last_kernel_ms(const siftmi_plan *p, float *total_ms, float *blur_ms, int32_t *blur_launches,
+                               double *blur_pixels) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (!p->profile) return fail(SIFTMI_EINVAL, "plan was created with profile=0");
+    float tot = 0;
+    HIPCHK(hipEventElapsedTime(&tot, p->ev_first, p->ev_last));
+    float bms = 0; int bl = 0; double px = 0;
+    for (size_t i = 0; i < p->n_events; i++)
+        if (p->events[i].is_blur) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, p->events[i].a, p->events[i].b);
+            bms += ms; bl++; px += p->events[i].pixels;
+        }
+    if (total_ms) *total_ms = tot;
+    if (blur_ms) *blur_ms = bms;
+    if (blur_launches) *blur_launches = bl;
+    if (blur_pixels) *blur_pixels = px;
+    return SIFTMI_OK;
+}
+
+// ============================================================================================
+// MatchPlan
+}  // extern "C"
+
+struct siftmi_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t size = 0;
+    int profile = 0;
+    uint8_t *kp1 = nullptr, *kp2 = nullptr;
+    int64_t cap1 = 0, cap2 = 0;
+    int2 *pairs = nullptr;
+    int64_t cap_pairs = 0;
+    int *counter = nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    float last_ms = 0;
+};
+
+namespace {
+int ensure(void **ptr, int64_t *cap, int64_t need, size_t elem) {
+    if (need <= *cap && *ptr) return SIFTMI_OK;
+    if (*ptr) hipFree(*ptr);
+    *ptr = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(ptr, (size_t)(need > 0 ? need : 1) * elem);
+    if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%lld x %zu): %s", (long long)need, elem, hipGetErrorString(e));
+    *cap = need;
+    return SIFTMI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int siftmi_match_create(int64_t size, int32_t device_id, int32_t profile, siftmi_matcher **out) {
+    if (!out) return fail(SIFTMI_EINVAL, "null argument");
+    *out = nullptr;
+    if (size < 1) return fail(SIFTMI_EINVAL, "size must be >= 1");
+    int ndev = siftmi_device_count();
+    if (ndev < 1) return fail(SIFTMI_EDEVICE, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(SIFTMI_EINVAL, "device %d out of range", device_id);
+    HIPCHK(hipSetDevice(device_id));
+    siftmi_matcher *m = new (std::nothrow) siftmi_matcher();
+    if (!m) return fail(SIFTMI_ENOMEM, "host allocation failed");
+    m->device = device_id; m->size = size; m->profile = profile;
+    int rc = SIFTMI_OK;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
+    if (!rc) rc = ensure((void **)&m->kp1, &m->cap1, size, 144);
+    if (!rc) rc = ensure((void **)&m->kp2, &m->cap2, size, 144);
+    if (!rc) rc = ensure((void **)&m->pairs, &m->cap_pairs, size, sizeof(int2));
+    if (!rc && hipMalloc((void **)&m->counter, 16) != hipSuccess) rc = fail(SIFTMI_ENOMEM, "hipMalloc failed");
+    if (!rc) { hipEventCreate(&m->ea); hipEventCreate(&m->eb); }
+    if (rc) { std::string keep = g_err; siftmi_match_destroy(m); g_err = keep; return rc; }
+    *out = m;
+    return SIFTMI_OK;
+}
+
+int siftmi_match_destroy(siftmi_matcher *m) {
+    if (!m) return SIFTMI_OK;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    if (m->kp1) hipFree(m->kp1);
+    if (m->kp2) hipFree(m->kp2);
+    if (m->pairs) hipFree(m->pairs);
+    if (m->counter) hipFree(m->counter);
+    if (m->ea) hipEventDestroy(m->ea);
+    if (m->eb) hipEventDestroy(m->eb);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+    return SIFTMI_OK;
+}
+
+int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
+                 const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th, int32_t *pairs,
+                 int64_t capacity, int64_t *n_out, int64_t *n_total) {
+    if (!m || !n_out) return fail(SIFTMI_EINVAL, "null argument");
+    if (n1 < 0 || n2 < 0 || n1 > 0x7fffffff || n2 > 0x7fffffff) return fail(SIFTMI_EINVAL, "bad list size");
+    if ((n1 > 0 && !kp1) || (n2 > 0 && !kp2)) return fail(SIFTMI_EINVAL, "null keypoint list");
+    HIPCHK(hipSetDevice(m->device));
+    *n_out = 0;
+    if (n_total) *n_total = 0;
+    if (n1 == 0 || n2 == 0) return SIFTMI_OK;   // dist1 == dist2 == 1e12 -> ratio 1, never < ratio_th
+    if (kp1_is_device || kp2_is_device) HIPCHK(hipDeviceSynchronize());
+    const uint8_t *d1 = (const uint8_t *)kp1, *d2 = (const uint8_t *)kp2;
+    int rc;
+    if (!kp1_is_device) {
+        if ((rc = ensure((void **)&m->kp1, &m->cap1, n1, 144))) return rc;
+        HIPCHK(hipMemcpyAsync(m->kp1, kp1, (size_t)n1 * 144, hipMemcpyHostToDevice, m->stream));
+        d1 = m->kp1;
+    }
+    if (!kp2_is_device) {
+        if ((rc = ensure((void **)&m->kp2, &m->cap2, n2, 144))) return rc;
+        HIPCHK(hipMemcpyAsync(m->kp2, kp2, (size_t)n2 * 144, hipMemcpyHostToDevice, m->stream));
+        d2 = m->kp2;
+    }
+    // match.py:241-243,252: output capacity = max(self.kpsize, min(n1, n2))
+    int64_t cap = m->size;
+    if ((n1 < n2 ? n1 : n2) > cap) cap = (n1 < n2 ? n1 : n2);
+    if ((rc = ensure((void **)&m->pairs, &m->cap_pairs, cap, sizeof(int2)))) return rc;
+    HIPCHK(hipMemsetAsync(m->counter, 0, 4, m->stream));
+    const int blocks = (int)((n1 + 256 * SIFT_MATCH_QPT - 1) / (256 * SIFT_MATCH_QPT));
+    hipEventRecord(m->ea, m->stream);
+    hipLaunchKernelGGL(match_kernel, dim3((unsigned)blocks), dim3(256), 0, m->stream, d1, (int)n1, d2, (int)n2, ratio_th,
+                       m->pairs, m->counter, (int)cap);
+    hipEventRecord(m->eb, m->stream);
+    int count = 0;
+    HIPCHK(hipMemcpyAsync(&count, m->counter, 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipGetLastError());
+    hipEventElapsedTime(&m->last_ms, m->ea, m->eb);
+    if (n_total) *n_total = count;
+    int64_t n = count < cap ? count : cap;
+    rc = SIFTMI_OK;
+    if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "pair capacity too small; result truncated"; }
+    if (n > 0) {
+        if (!pairs) return fail(SIFTMI_EINVAL, "null pairs buffer");
+        HIPCHK(hipMemcpy(pairs, m->pairs, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return rc;
+}
+
+int siftmi_match_last_kernel_ms(const siftmi_matcher *m, float *ms) {
+    if (!m || !ms) return fail(SIFTMI_EINVAL, "null argument");
+    *ms = m->last_ms;
+    return SIFTMI_OK;
+}
+
+}  // extern "C"
+
+// ============================================================================================
+// Per-stage entry points: host arrays in, one kernel, host arrays out.
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t n) {
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        return e == hipSuccess ? SIFTMI_OK : fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+    }
+    int upload(const void *h, size_t n) {
+        int rc = alloc(n);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(p, h, n, hipMemcpyHostToDevice));
+        return SIFTMI_OK;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+
+int stage_begin(int device_id) {
+    int ndev = siftmi_device_count();
+    if (ndev < 1) return fail(SIFTMI_EDEVICE, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(SIFTMI_EINVAL, "device %d out of range", device_id);
+    HIPCHK(hipSetDevice(device_id));
+    return SIFTMI_OK;
+}
+
+int stage_end() {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipGetLastError());
+    return SIFTMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int siftmi_stage_gaussian_taps(float sigma, int32_t size, float *out) {
+    if (!out) return fail(SIFTMI_EINVAL, "null argument");
+    return gaussian_taps(sigma, size, out);
+}
+
+int siftmi_stage_minmax_normalize(int32_t dev, const float *in, float *out, int32_t W, int32_t H, float *mn, float *mx) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    const size_t N = (size_t)W * H;
+    DevBuf a, b, mm;
+    if ((rc = a.upload(in, N * 4)) || (rc = b.alloc(N * 4)) || (rc = mm.alloc(8))) return rc;
+    hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, 0, mm.as<uint32_t>());
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, 2048)), dim3(256), 0, 0, a.as<float>(), (int64_t)N, mm.as<uint32_t>());
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for((int64_t)N, 256, 4096)), dim3(256), 0, 0, a.as<float>(), b.as<float>(), (int64_t)N, (const uint32_t *)mm.as<uint32_t>());
+    if ((rc = stage_end())) return rc;
+    uint32_t h[2];
+    HIPCHK(hipMemcpy(h, mm.p, 8, hipMemcpyDeviceToHost));
+    auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
+    if (mn) *mn = dec(h[0]);
+    if (mx) *mx = dec(h[1]);
+    if (out) HIPCHK(hipMemcpy(out, b.p, N * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_blur(int32_t dev, const float *in, float *out, int32_t W, int32_t H, const float *taps, int32_t ntaps) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    if (ntaps < 1 || ntaps > 64) return fail(SIFTMI_EINVAL, "ntaps must be in 1..64");
+    const size_t N = (size_t)W * H;
+    DevBuf a, b, t, dt;
+    if ((rc = a.upload(in, N * 4)) || (rc = b.alloc(N * 4)) || (rc = t.alloc(N * 4))) return rc;
+    Taps tp; tp.n = ntaps;
+    for (int i = 0; i < ntaps; i++) tp.t[i] = taps[i];
+    if ((rc = dt.upload(tp.t, sizeof tp.t))) return rc;
+    tp.dev = dt.as<float>();
+    if (!launch_blur_tiled<false>(0, a.as<float>(), b.as<float>(), W, H, tp, nullptr))
+        launch_blur_generic(0, a.as<float>(), b.as<float>(), t.as<float>(), W, H, tp, nullptr, false);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(out, b.p, N * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_dog(int32_t dev, const float *blur_a, const float *blur_b, float *out, int64_t n) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    DevBuf a, b, o;
+    if ((rc = a.upload(blur_a, (size_t)n * 4)) || (rc = b.upload(blur_b, (size_t)n * 4)) || (rc = o.alloc((size_t)n * 4))) return rc;
+    hipLaunchKernelGGL(dog_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, 0, a.as<float>(), b.as<float>(), o.as<float>(), n);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(out, o.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_local_maxmin(int32_t dev, const float *blurs, int32_t W, int32_t H, int32_t octsize,
+                              const siftmi_params *par, float *out, int64_t capacity, int64_t *n_out) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    if (!par || !n_out) return fail(SIFTMI_EINVAL, "null argument");
+    const size_t N = (size_t)W * H;
+    DevBuf b, c, cnt;
+    if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = c.alloc((size_t)capacity * 16)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
+    HIPCHK(hipMemset(cnt.p, 0, sizeof(Counters)));
+    BlurPlanes bp;
+    for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
+    const int border = par->border_dist;
+    if (W > 2 * border && H > 2 * border) {
+        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
+        const float edth = (octsize <= 1) ? par->edge_thresh0 : par->edge_thresh;
+        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border,
+                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand, (int)capacity);
+    }
+    if ((rc = stage_end())) return rc;
+    Counters hc;
+    HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
+    int64_t n = hc.n_cand < capacity ? hc.n_cand : capacity;
+    if (n > 0) HIPCHK(hipMemcpy(out, c.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    *n_out = n;
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_interp(int32_t dev, const float *blurs, int32_t W, int32_t H, const float *cand, int64_t n,
+                        const siftmi_params *par, float *out, int32_t *out_scale, int64_t *n_out) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    if (!par || !n_out) return fail(SIFTMI_EINVAL, "null argument");
+    const size_t N = (size_t)W * H;
+    DevBuf b, c, k, ks, cnt;
+    if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = c.upload(cand, (size_t)n * 16)) || (rc = k.alloc((size_t)n * 16)) ||
+        (rc = ks.alloc((size_t)n * 4)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
+    Counters hc{};
+    hc.n_cand = (int)n;
+    HIPCHK(hipMemcpy(cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice));
+    BlurPlanes bp;
+    for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
+    Counters *dc = cnt.as<Counters>();
+    hipLaunchKernelGGL(refine_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, 0, bp, W, H, (const float4 *)c.as<float4>(),
+                       (const int *)&dc->n_cand, (int)n, par->peak_thresh, (float)par->init_sigma, k.as<float4>(),
+                       ks.as<int>(), &dc->n_kp, (int)n);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
+    const int64_t m = hc.n_kp;
+    if (m > 0) {
+        HIPCHK(hipMemcpy(out, k.p, (size_t)m * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_scale, ks.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    }
+    *n_out = m;
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_gradient(int32_t dev, const float *img, float *grad, float *ori, int32_t W, int32_t H) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    const size_t N = (size_t)W * H;
+    DevBuf a, g, o;
+    if ((rc = a.upload(img, N * 4)) || (rc = g.alloc(N * 4)) || (rc = o.alloc(N * 4))) return rc;
+    hipLaunchKernelGGL(gradient_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, 0, a.as<float>(),
+                       g.as<float>(), o.as<float>(), W, H);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(grad, g.p, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ori, o.p, N * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t H, int32_t octsize, const float *kps,
+                             const int32_t *kp_scale, int64_t n, const siftmi_params *par, float *out,
+                             int32_t *out_scale, int64_t capacity, int64_t *n_out) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    if (!par || !n_out) return fail(SIFTMI_EINVAL, "null argument");
+    const size_t N = (size_t)W * H;
+    DevBuf b, k, ks, o, oa, cnt;
+    if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = k.upload(kps, (size_t)n * 16)) || (rc = ks.upload(kp_scale, (size_t)n * 4)) ||
+        (rc = o.alloc((size_t)capacity * 16)) || (rc = oa.alloc((size_t)capacity * 4)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
+    Counters hc{};
+    hc.n_kp = (int)n;
+    HIPCHK(hipMemcpy(cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice));
+    BlurPlanes bp;
+    for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
+    hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, bp, W, H, octsize,
+                       par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), (int)n,
+                       o.as<float4>(), oa.as<int>(), (int)capacity, (int)capacity);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
+    int64_t m = hc.n_out < capacity ? hc.n_out : capacity;
+    if (m > 0) {
+        HIPCHK(hipMemcpy(out, o.p, (size_t)m * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_scale, oa.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    }
+    *n_out = m;
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t H, int32_t octsize, const float *kps,
+                            const int32_t *kp_scale, int64_t n, uint8_t *desc) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    const size_t N = (size_t)W * H;
+    DevBuf b, k, ks, r;
+    if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = k.upload(kps, (size_t)n * 16)) || (rc = ks.upload(kp_scale, (size_t)n * 4)) ||
+        (rc = r.alloc((size_t)n * sizeof(KpRecord)))) return rc;
+    BlurPlanes bp;
+    for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
+    if (n > 0)
+        hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(64), 0, 0, bp, W, H, octsize,
+                           (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, (int)n,
+                           (int)n, r.as<KpRecord>());
+    if ((rc = stage_end())) return rc;
+    std::vector<KpRecord> h((size_t)n);
+    if (n > 0) HIPCHK(hipMemcpy(h.data(), r.p, (size_t)n * sizeof(KpRecord), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) memcpy(desc + (size_t)i * 128, h[(size_t)i].desc, 128);
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_shrink(int32_t dev, const float *in, float *out, int32_t W, int32_t H) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    const int SW = W / 2, SH = H / 2;
+    DevBuf a, o;
+    if ((rc = a.upload(in, (size_t)W * H * 4)) || (rc = o.alloc((size_t)SW * SH * 4))) return rc;
+    if (SW > 0 && SH > 0)
+        hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, 0, a.as<float>(), o.as<float>(), W, SW, SH);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(out, o.p, (size_t)SW * SH * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_convert(int32_t dev, const void *in, int32_t dt, float *out, int32_t W, int32_t H) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    const size_t N = (size_t)W * H;
+    if (dtype_size(dt) == 0) return fail(SIFTMI_EINVAL, "invalid input format (%d)", dt);
+    DevBuf a, o;
+    if ((rc = a.upload(in, N * dtype_size(dt))) || (rc = o.alloc(N * 4))) return rc;
+    const int g = grid_for((int64_t)N, 256, 4096);
+    switch (dt) {
+        case SIFTMI_F32: HIPCHK(hipMemcpy(o.p, a.p, N * 4, hipMemcpyDeviceToDevice)); break;
+        case SIFTMI_U8: hipLaunchKernelGGL(convert_kernel<uint8_t>, dim3(g), dim3(256), 0, 0, a.as<uint8_t>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_U16: hipLaunchKernelGGL(convert_kernel<uint16_t>, dim3(g), dim3(256), 0, 0, a.as<uint16_t>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_U32: hipLaunchKernelGGL(convert_kernel<uint32_t>, dim3(g), dim3(256), 0, 0, a.as<uint32_t>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_U64: hipLaunchKernelGGL(convert_kernel<uint64_t>, dim3(g), dim3(256), 0, 0, a.as<uint64_t>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_I32: hipLaunchKernelGGL(convert_kernel<int32_t>, dim3(g), dim3(256), 0, 0, a.as<int32_t>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_I64: hipLaunchKernelGGL(convert_kernel<int64_t>, dim3(g), dim3(256), 0, 0, a.as<int64_t>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_F64: hipLaunchKernelGGL(convert_kernel<double>, dim3(g), dim3(256), 0, 0, a.as<double>(), o.as<float>(), (int64_t)N); break;
+        case SIFTMI_RGB8: hipLaunchKernelGGL(convert_rgb_kernel, dim3(g), dim3(256), 0, 0, a.as<uint8_t>(), o.as<float>(), (int64_t)N); break;
+    }
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(out, o.p, N * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_stage_math(int32_t dev, int32_t fn, const float *a, const float *b, float *out, int64_t n) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    DevBuf da, db, o;
+    if ((rc = da.upload(a, (size_t)n * 4)) || (rc = db.upload(b ? b : a, (size_t)n * 4)) || (rc = o.alloc((size_t)n * 4))) return rc;
+    hipLaunchKernelGGL(math_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, 0, fn, da.as<float>(), db.as<float>(), o.as<float>(), n);
+    if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(out, o.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+"""SiftPlan -- keypoint extraction on one MI355X through libsiftmi.so.
+
+Host-side mirror of the reference's ``sift_pyocl.SiftPlan`` (sift-src/plan.py:70-867): same
+constructor keywords, attributes, ``keypoints()`` / ``__call__`` contract, exceptions and output
+record type, so code written against the reference runs unchanged.  All arithmetic happens in the
+hand-written HIP kernels; this class only validates arguments, marshals pointers and wraps the
+result.  There is no PyOpenCL, no CPU fallback and no per-stage host round trip.
+"""
+import ctypes as C
+import logging
+import math
+import os
+import threading
+import time
+
+import numpy
+
+from . import _lib
+from .param import par
+from .utils import calc_size, kernel_size, nextpower
+
+logger = logging.getLogger("sift.plan")
+
+
+def _pointer_of(image):
+    """(pointer, is_device, dtype, shape, keepalive) for numpy arrays, torch tensors (host or
+    HIP) or any object exposing __cuda_array_interface__ (the analogue of the reference accepting
+    pyopencl.array.Array inputs, plan.py:451-452)."""
+    if isinstance(image, numpy.ndarray):
+        if not image.flags["C_CONTIGUOUS"]:
+            image = numpy.ascontiguousarray(image)              # plan.py:446-447
+        return image.ctypes.data, 0, image.dtype, image.shape, image
+    if hasattr(image, "data_ptr") and hasattr(image, "is_cuda"):   # torch.Tensor
+        t = image if image.is_contiguous() else image.contiguous()
+        np_dtype = numpy.dtype(str(t.dtype).replace("torch.", ""))
+        if t.is_cuda:
+            return t.data_ptr(), 1, np_dtype, tuple(t.shape), t
+        arr = t.numpy()
+        return arr.ctypes.data, 0, arr.dtype, arr.shape, arr
+    cai = getattr(image, "__cuda_array_interface__", None)
+    if cai is not None:
+        if cai.get("strides") is not None:
+            raise RuntimeError("device arrays must be C-contiguous")
+        return cai["data"][0], 1, numpy.dtype(cai["typestr"]), tuple(cai["shape"]), image
+    arr = numpy.ascontiguousarray(image)
+    return arr.ctypes.data, 0, arr.dtype, arr.shape, arr
+
+
+class SiftPlan(object):
+    """Plan to compute SIFT keypoints of images of one shape and type.
+
+    ::
+
+        siftp = sift_pyocl_amd.SiftPlan(img.shape, img.dtype, devicetype="GPU")
+        kp = siftp.keypoints(img)
+
+    ``kp`` is a numpy recarray with fields x, y, scale, angle and desc (128 x uint8), as in the
+    reference (plan.py:110-115).
+
+    Differences that are deliberate: the computation always runs on the MI355X selected by
+    ``device`` (an integer HIP ordinal, or the reference's ``(platform, device)`` tuple whose
+    second element is used); ``devicetype`` is accepted for compatibility -- the numerics are
+    always those of the reference's CPU kernel variants (orientation_cpu / keypoints_cpu), which
+    is what ``USE_CPU`` reports.  ``octave_max`` (extension) limits the number of octaves.
+    """
+
+    converter = {numpy.dtype(numpy.uint8): "u8_to_float",
+                 numpy.dtype(numpy.uint16): "u16_to_float",
+                 numpy.dtype(numpy.uint32): "u32_to_float",
+                 numpy.dtype(numpy.uint64): "u64_to_float",
+                 numpy.dtype(numpy.int32): "s32_to_float",
+                 numpy.dtype(numpy.int64): "s64_to_float",
+                 }
+    sigmaRatio = 2.0 ** (1.0 / par.Scales)
+    PIX_PER_KP = 10
+    dtype_kp = numpy.dtype([('x', numpy.float32),
+                            ('y', numpy.float32),
+                            ('scale', numpy.float32),
+                            ('angle', numpy.float32),
+                            ('desc', (numpy.uint8, 128))
+                            ])
+
+    def __init__(self, shape=None, dtype=None, devicetype="CPU", template=None,
+                 profile=False, device=None, PIX_PER_KP=None,
+                 max_workgroup_size=None, context=None, init_sigma=None, octave_max=None):
+        if init_sigma is None:
+            init_sigma = par.InitSigma
+        self._init_sigma = float(init_sigma)
+        if template is not None:
+            self.shape = tuple(template.shape)
+            self.dtype = numpy.dtype(str(template.dtype).replace("torch.", ""))
+        else:
+            self.shape = tuple(shape)
+            self.dtype = numpy.dtype(dtype)
+        if len(self.shape) == 3:
+            self.RGB = True
+            self.shape = self.shape[:2]
+        elif len(self.shape) == 2:
+            self.RGB = False
+        else:
+            raise RuntimeError("Unable to process image of shape %s" % (tuple(self.shape,)))
+        if PIX_PER_KP:
+            self.PIX_PER_KP = int(PIX_PER_KP)
+        if par.Scales != 3:
+            raise RuntimeError("par.Scales is hard-wired to 3 in the kernels (as in image.cl:355)")
+        self.profile = bool(profile)
+        self.events = []
+        self._sem = threading.Semaphore()
+        self.scales = []     # octave sizes in XY order, as the reference
+        self.procsize = []
+        self.wgsize = []
+        self.max_workgroup_size = max_workgroup_size or 4096   # accepted, unused
+        self.ctx = context                                      # accepted, unused
+        self._calc_scales()
+        self._octave_limit = int(octave_max) if octave_max else 0
+        if self._octave_limit:
+            self.octave_max = min(self.octave_max, self._octave_limit)
+        self._calc_memory()
+        self.LOW_END = 0
+        if isinstance(device, (tuple, list)):
+            device = device[-1]
+        if device is None:
+            device = int(os.environ.get("SIFT_MI355X_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+        self.device = int(device)
+        self.devicetype = "GPU"
+        self.USE_CPU = (str(devicetype).upper() == "CPU")   # selects the CPU-variant numerics: always used here
+        if self.RGB:
+            if self.dtype != numpy.uint8:
+                raise RuntimeError("invalid input format error (RGB needs uint8)")
+            self._code = _lib.DTYPE_CODES["rgb8"]
+        elif self.dtype == numpy.float64:
+            self._code = _lib.DTYPE_CODES["float32"]        # host cast, as plan.py:457-463
+        elif self.dtype == numpy.float32 or self.dtype in self.converter:
+            self._code = _lib.DTYPE_CODES[self.dtype.name]
+        else:
+            raise RuntimeError("invalid input format error (%s)" % (str(self.dtype)))
+        self._handle = C.c_void_p()
+        L = _lib.lib()
+        if L.siftmi_device_count() < 1:
+            raise RuntimeError("sift_pyocl_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
+        self._params = self._current_params()
+        _lib.check(L.siftmi_plan_create(self.shape[0], self.shape[1], self._code, self.device,
+                                        C.byref(self._params), int(self.profile), C.byref(self._handle)))
+        nbytes = C.c_int64()
+        _lib.check(L.siftmi_plan_info(self._handle, None, None, C.byref(nbytes)))
+        self.memory = int(nbytes.value)
+        self._out = numpy.empty(self.kpsize, dtype=self.dtype_kp)
+        self.overflow = False
+        self.debug = []
+
+    # ------------------------------------------------------------------ sizing (plan.py:213-266)
+    def _calc_scales(self):
+        shape = self.shape[-1::-1]
+        self.scales = [tuple(numpy.int32(i) for i in shape)]
+        min_size = 2 * par.BorderDist + 2
+        while min(shape) > min_size:
+            shape = tuple(numpy.int32(i // 2) for i in shape)
+            self.scales.append(shape)
+        self.scales.pop()
+        self.octave_max = len(self.scales)
+        for s in self.scales:
+            wg = (min(nextpower(int(s[0])), 4096), 1)
+            self.wgsize.append(wg)
+            self.procsize.append(calc_size(s, wg))
+
+    def _calc_memory(self):
+        self.kpsize = max(1, int(self.shape[0] * self.shape[1] // self.PIX_PER_KP))
+        self.red_size = nextpower(min(4096, math.sqrt(self.shape[0] * self.shape[1])))
+
+    def gaussian_sizes(self):
+        """[(sigma, taps)] of the initial blur (if any) and of the five per-octave blurs."""
+        out = []
+        cur = 1.0 if par.DoubleImSize else 0.5
+        if self._init_sigma > cur:
+            s = math.sqrt(self._init_sigma ** 2 - cur ** 2)
+            out.append((s, kernel_size(s, True)))
+        prev = self._init_sigma
+        for _ in range(par.Scales + 2):
+            inc = prev * math.sqrt(self.sigmaRatio ** 2 - 1.0)
+            out.append((inc, kernel_size(inc, True)))
+            prev *= self.sigmaRatio
+        return out
+
+    def _current_params(self):
+        if par.DoubleImSize:
+            raise RuntimeError("par.DoubleImSize is not supported (neither does the reference implement it)")
+        return _lib.Params(init_sigma=self._init_sigma,
+                           peak_thresh=numpy.float32(par.PeakThresh),
+                           edge_thresh0=numpy.float32(par.EdgeThresh1),
+                           edge_thresh=numpy.float32(par.EdgeThresh),
+                           ori_sigma=numpy.float32(par.OriSigma),
+                           border_dist=int(par.BorderDist),
+                           octave_max=self._octave_limit,
+                           pix_per_kp=int(self.PIX_PER_KP), reserved=0)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.lib().siftmi_plan_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # ------------------------------------------------------------------ the hot path
+    def keypoints(self, image):
+        """Calculates the keypoints of the image
+
+        :param image: 2D array (3D if RGB): numpy, or a device-resident torch tensor
+        :return: numpy recarray of keypoints (x, y, scale, angle, desc[128])
+        """
+        self.reset_timer()
+        with self._sem:
+            t0 = time.time()
+            ptr, is_dev, dtype, shape, keep = _pointer_of(image)
+            assert tuple(shape[:2]) == tuple(self.shape)
+            assert dtype in [self.dtype, numpy.float32]
+            if dtype == numpy.float32 and len(shape) == 2:
+                code = _lib.DTYPE_CODES["float32"]
+            elif self.dtype == numpy.float64 and dtype == numpy.float64:
+                if is_dev:
+                    keep = keep.float()
+                    ptr = keep.data_ptr()
+                else:
+                    keep = keep.astype(numpy.float32)
+                    ptr = keep.ctypes.data
+                code = _lib.DTYPE_CODES["float32"]
+            elif len(shape) == 3 and dtype == numpy.uint8 and self.RGB:
+                code = _lib.DTYPE_CODES["rgb8"]
+            elif self.dtype in self.converter and len(shape) == 2:
+                code = _lib.DTYPE_CODES[self.dtype.name]
+            else:
+                raise RuntimeError("invalid input format error (%s)" % (str(self.dtype)))
+            L = _lib.lib()
+            params = self._current_params()
+            if bytes(params) != bytes(self._params):
+                _lib.check(L.siftmi_plan_set_params(self._handle, C.byref(params)))
+                self._params = params
+            n = C.c_int64(0)
+            ovf = C.c_int32(0)
+            rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, self._out.ctypes.data, 0,
+                                         self._out.size, C.byref(n), C.byref(ovf))
+            _lib.check(rc, allow=(_lib.ECAPACITY,))
+            self.overflow = bool(ovf.value) or rc == _lib.ECAPACITY
+            if self.overflow:
+                logger.warning("Keypoint counter overflow: more than %s keypoints, result truncated", self.kpsize)
+            output = self._out[:n.value].copy().view(numpy.recarray)
+            del keep
+            logger.info("Execution time: %.3fms" % (1000 * (time.time() - t0)))
+        return output
+
+    __call__ = keypoints
+
+    def minmax(self):
+        """(min, max) of the last processed image (buffers["min"], buffers["max"] in the reference)."""
+        mn, mx = C.c_float(), C.c_float()
+        _lib.check(_lib.lib().siftmi_plan_get_minmax(self._handle, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    # ------------------------------------------------------------------ profiling (plan.py:826-857)
+    def _profile_lines(self):
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(_lib.lib().siftmi_plan_profile(self._handle, buf, len(buf)))
+        out = []
+        for line in buf.value.decode().splitlines():
+            label, ms = line.rsplit("\t", 1)
+            out.append((label, float(ms)))
+        return out
+
+    def kernel_times(self):
+        """dict(total_ms, blur_ms, blur_launches, blur_pixels) of the last call (profile=True)."""
+        tot, blur = C.c_float(), C.c_float()
+        nl, px = C.c_int32(), C.c_double()
+        _lib.check(_lib.lib().siftmi_plan_last_kernel_ms(self._handle, C.byref(tot), C.byref(blur), C.byref(nl), C.byref(px)))
+        return dict(total_ms=tot.value, blur_ms=blur.value, blur_launches=nl.value, blur_pixels=px.value)
+
+    def log_profile(self):
+        """If profiling is on, print the device time of every stage of the last call."""
+        t = orient = descr = 0.0
+        if self.profile:
+            for label, et in self._profile_lines():
+                print("%50s:\t%.3fms" % (label, et))
+                t += et
+                if "orient" in label:
+                    orient += et
+                if "descriptors" in label:
+                    descr += et
+        print("_" * 80)
+        print("%50s:\t%.3fms" % ("Total execution time", t))
+        print("%50s:\t%.3fms" % ("Total Orientation assignment", orient))
+        print("%50s:\t%.3fms" % ("Total Descriptors", descr))
+
+    def reset_timer(self):
+        with self._sem:
+            self.events = []

@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Tolerances: none.  Integer/byte outputs (descriptors, match pairs) and every float field
+(x, y, scale, angle, intermediate planes) must be bit-identical to oracle/sift_oracle.c, which is
+itself pinned to the reference's natively compiled kernels (tests/test_oracle_vs_ref.py,
+tests/golden/).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import (assert_same_keypoints, multiscale_noise, rectangles, smooth_noise, sort_rows, white_noise)
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _params(**kw):
+    from sift_pyocl_amd import _lib
+    d = dict(init_sigma=1.6, peak_thresh=np.float32(255.0 * 0.04 / 3.0), edge_thresh0=np.float32(0.08),
+             edge_thresh=np.float32(0.06), ori_sigma=np.float32(1.5), border_dist=5, octave_max=0, pix_per_kp=10,
+             reserved=0)
+    d.update(kw)
+    return _lib.Params(**d)
+
+
+# ----------------------------------------------------------------------------- siftmath
+@pytest.mark.parametrize("fn", [0, 1, 2, 3, 4])
+def test_device_math_bit_exact(siftlib, oracle, fn):
+    rng = np.random.default_rng(fn)
+    n = 200000
+    if fn == 0:
+        a = (-rng.random(n) * 110).astype(np.float32); a[:8] = [0, -0.0, -1e-30, -88.5, -103.9, -104.5, 1.0, np.nan]
+    elif fn == 1:
+        a = (rng.random(n) * 12 - 6).astype(np.float32)
+    elif fn in (2, 3):
+        a = (rng.random(n) * 8 - 4).astype(np.float32); a[:4] = [0, np.pi, -np.pi, 3.1415927]
+    else:
+        a = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 3, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 3, n)).astype(np.float32)
+    if fn == 4:
+        a[:6] = [0, -0.0, 0, 1, -1, 0]; b[:6] = [0, 0, -0.0, 0, 0, -1]
+    out = np.empty(n, np.float32)
+    assert siftlib.siftmi_stage_math(0, fn, _p(a), _p(b), _p(out), n) == 0
+    L = oracle.lib()
+    exp = np.empty(n, np.float32)
+    s, c = C.c_float(), C.c_float()
+    for i in range(n):
+        if fn == 0: exp[i] = L.so_expf(C.c_float(a[i]))
+        elif fn == 1: exp[i] = L.so_exp2f(C.c_float(a[i]))
+        elif fn in (2, 3):
+            L.so_sincosf(C.c_float(a[i]), C.byref(s), C.byref(c)); exp[i] = s.value if fn == 2 else c.value
+        else: exp[i] = L.so_atan2f(C.c_float(a[i]), C.c_float(b[i]))
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+
+
+# ----------------------------------------------------------------------------- stages
+def test_gaussian_taps(siftlib, oracle):
+    for sigma, size in [(1.5198684, 15), (1.2262735, 11), (1.5450078, 15), (1.9465878, 17), (2.452547, 21), (3.0900156, 27),
+                        (3.0, 28), (0.7, 7)]:
+        out = np.empty(size, np.float32)
+        assert siftlib.siftmi_stage_gaussian_taps(C.c_float(sigma), size, _p(out)) == 0
+        assert np.array_equal(out, oracle.gaussian_taps(sigma, size))
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (131, 97), (300, 421), (16, 16), (13, 700), (1025, 1030)])
+@pytest.mark.parametrize("ntaps", [11, 15, 17, 21, 27, 9, 28])
+def test_blur_bit_exact(siftlib, oracle, shape, ntaps):
+    if min(shape) < ntaps - ((ntaps - 1) // 2):
+        pytest.skip("image smaller than the filter half-width: undefined in the reference too (convolution.cl:45-48)")
+    img = white_noise(shape, seed=ntaps) * 255
+    taps = oracle.gaussian_taps(ntaps / 8.0, ntaps)
+    out = np.empty_like(img)
+    assert siftlib.siftmi_stage_blur(0, _p(img), _p(out), shape[1], shape[0], _p(taps), ntaps) == 0
+    exp = oracle.blur(img, taps)
+    assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
+
+
+def test_minmax_normalize(siftlib, oracle):
+    for shape in [(512, 512), (131, 97), (1980, 2560)]:
+        img = (white_noise(shape, 1) - 0.3) * 1000
+        out = np.empty_like(img)
+        mn, mx = C.c_float(), C.c_float()
+        assert siftlib.siftmi_stage_minmax_normalize(0, _p(img), _p(out), shape[1], shape[0], C.byref(mn), C.byref(mx)) == 0
+        assert mn.value == img.min() and mx.value == img.max()
+        assert np.array_equal(out, oracle.normalize(img, img.min(), img.max()))
+
+
+def _octave_blurs(oracle, img):
+    """blur[0..5] of the first octave of `img` computed by the oracle (normalise, init blur, 5 blurs)."""
+    import math
+    mn, mx = oracle.minmax(img)
+    base = oracle.normalize(img, mn, mx)
+    s0 = math.sqrt(1.6 ** 2 - 0.25)
+    base = oracle.blur(base, oracle.gaussian_taps(s0, 15))
+    blurs = [base]
+    ratio = 2.0 ** (1.0 / 3.0)
+    prev = 1.6
+    for s in range(5):
+        inc = prev * math.sqrt(ratio ** 2 - 1.0)
+        size = int(math.ceil(8 * inc + 1)); size += (size % 2 == 0)
+        blurs.append(oracle.blur(blurs[-1], oracle.gaussian_taps(inc, size)))
+        prev *= ratio
+    return np.ascontiguousarray(np.stack(blurs))
+
+
+@pytest.mark.parametrize("maker,shape", [(smooth_noise, (131, 97)), (white_noise, (256, 300)), (multiscale_noise, (300, 421))])
+def test_detection_stages(siftlib, oracle, maker, shape):
+    img = maker(shape)
+    H, W = shape
+    blurs = _octave_blurs(oracle, img)
+    par = _params()
+    opar = oracle.default_params()
+    dogs = oracle.dog(blurs)
+    # DoG stage
+    d = np.empty_like(dogs[0])
+    assert siftlib.siftmi_stage_dog(0, _p(blurs[2]), _p(blurs[3]), _p(d), d.size) == 0
+    assert np.array_equal(d, dogs[2])
+    # extrema of the three scales
+    cap = H * W // 10
+    exp_all = []
+    for s in (1, 2, 3):
+        k, n = oracle.local_maxmin(dogs, s, 1, cap, opar)
+        exp_all.append(k[:n])
+    exp = np.concatenate(exp_all)
+    got = np.empty((cap, 4), np.float32)
+    n = C.c_int64()
+    assert siftlib.siftmi_stage_local_maxmin(0, _p(blurs), W, H, 1, C.byref(par), _p(got), cap, C.byref(n)) == 0
+    assert n.value == len(exp)
+    assert np.array_equal(sort_rows(got[:n.value]), sort_rows(exp))
+    # refinement + compaction
+    cand = np.ascontiguousarray(exp)
+    interp = oracle.interp_keypoint(dogs, cand, 0, len(cand), opar)
+    keep = interp[:, 1] != -1
+    exp_ref = np.concatenate([interp[keep], cand[keep][:, 3:4]], axis=1)
+    ref = np.empty((len(cand), 4), np.float32); sc = np.empty(len(cand), np.int32)
+    m = C.c_int64()
+    assert siftlib.siftmi_stage_interp(0, _p(blurs), W, H, _p(cand), len(cand), C.byref(par), _p(ref), _p(sc), C.byref(m)) == 0
+    assert m.value == keep.sum()
+    got_ref = np.concatenate([ref[:m.value], sc[:m.value, None].astype(np.float32)], axis=1)
+    assert np.array_equal(sort_rows(got_ref).view(np.uint32), sort_rows(exp_ref).view(np.uint32))
+    # gradient maps
+    g = np.empty((H, W), np.float32); o = np.empty((H, W), np.float32)
+    assert siftlib.siftmi_stage_gradient(0, _p(blurs[2]), _p(g), _p(o), W, H) == 0
+    eg, eo = oracle.gradient(blurs[2])
+    assert np.array_equal(g.view(np.uint32), eg.view(np.uint32))
+    assert np.array_equal(o.view(np.uint32), eo.view(np.uint32))
+    # orientation + descriptor per detection scale
+    for s in (1, 2, 3):
+        sel = exp_ref[exp_ref[:, 4] == s][:, :4].copy()
+        if len(sel) == 0:
+            continue
+        eg, eo = oracle.gradient(blurs[s])
+        buf = np.full((len(sel) * 4 + 8, 4), -1, np.float32); buf[:len(sel)] = sel
+        okp, cnt = oracle.orientation(buf, eg, eo, 1, 0, len(sel), capacity=len(buf), par=opar)
+        okp = okp[:cnt]
+        edesc = oracle.descriptor(okp, eg, eo, 1, 0, cnt)[:cnt]
+        valid = ~np.isnan(okp.sum(axis=1))
+        scl = np.full(len(sel), s, np.int32)
+        out = np.empty((len(buf), 4), np.float32); osc = np.empty(len(buf), np.int32); no = C.c_int64()
+        assert siftlib.siftmi_stage_orientation(0, _p(blurs), W, H, 1, _p(sel), _p(scl), len(sel), C.byref(par), _p(out),
+                                                _p(osc), len(buf), C.byref(no)) == 0
+        assert no.value == valid.sum()
+        assert np.array_equal(sort_rows(out[:no.value]).view(np.uint32), sort_rows(okp[valid]).view(np.uint32))
+        # descriptors for the oracle's oriented list (same order -> direct comparison)
+        kk = np.ascontiguousarray(okp[valid]); ss = np.full(len(kk), s, np.int32)
+        dd = np.zeros((len(kk), 128), np.uint8)
+        assert siftlib.siftmi_stage_descriptor(0, _p(blurs), W, H, 1, _p(kk), _p(ss), len(kk), _p(dd)) == 0
+        assert np.array_equal(dd, edesc[valid]), "descriptor bins differ at scale %d" % s
+
+
+def test_shrink_and_convert(siftlib):
+    img = white_noise((301, 203), 2)
+    out = np.empty((150, 101), np.float32)
+    assert siftlib.siftmi_stage_shrink(0, _p(img), _p(out), 203, 301) == 0
+    assert np.array_equal(out, img[:300:2, :202:2])
+    rng = np.random.default_rng(0)
+    from sift_pyocl_amd._lib import DTYPE_CODES
+    for name in ("uint8", "uint16", "uint32", "uint64", "int32", "int64", "float64"):
+        dt = np.dtype(name)
+        if dt.kind == "f":
+            a = rng.standard_normal((50, 70)).astype(dt)
+        else:
+            info = np.iinfo(dt)
+            a = rng.integers(info.min, info.max, (50, 70), dtype=dt, endpoint=True)
+        o = np.empty((50, 70), np.float32)
+        assert siftlib.siftmi_stage_convert(0, _p(a), DTYPE_CODES[name], _p(o), 70, 50) == 0
+        assert np.array_equal(o, a.astype(np.float32)), name
+    rgb = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    o = np.empty((40, 60), np.float32)
+    assert siftlib.siftmi_stage_convert(0, _p(rgb), DTYPE_CODES["rgb8"], _p(o), 60, 40) == 0
+    f = rgb.astype(np.float32)
+    exp = (np.float32(0.299) * f[..., 0] + np.float32(0.587) * f[..., 1]) + np.float32(0.114) * f[..., 2]
+    assert np.array_equal(o, exp)
+
+
+# ----------------------------------------------------------------------------- whole pipeline
+CASES = [("white512", white_noise, (512, 512)), ("smooth512", smooth_noise, (512, 512)),
+         ("multi300x421", multiscale_noise, (300, 421)), ("rect257x511", rectangles, (257, 511)),
+         ("smooth131x97", smooth_noise, (131, 97)), ("tiny16", white_noise, (16, 16)),
+         ("white1024x768", white_noise, (1024, 768))]
+
+
+@pytest.mark.parametrize("name,maker,shape", CASES)
+def test_keypoints_bit_exact_vs_oracle(siftlib, oracle, name, maker, shape):
+    import sift_pyocl_amd as sp
+    img = maker(shape)
+    plan = sp.SiftPlan(template=img, devicetype="CPU")
+    got = plan.keypoints(img)
+    exp = oracle.keypoints(img)
+    assert_same_keypoints(got, exp, name)
+    # a plan is reusable and deterministic as a set
+    again = plan.keypoints(img)
+    assert_same_keypoints(got, again, name + " (second call)")
+
+
+def test_keypoints_octave_limit_and_profile(siftlib, oracle):
+    import sift_pyocl_amd as sp
+    img = smooth_noise((512, 512))
+    plan = sp.SiftPlan(template=img, octave_max=3, profile=True)
+    got = plan.keypoints(img)
+    exp = oracle.keypoints(img, oracle.default_params(octave_max=3))
+    assert_same_keypoints(got, exp, "octave_max=3")
+    kt = plan.kernel_times()
+    assert kt["total_ms"] > 0 and kt["blur_launches"] == 16 and kt["blur_ms"] <= kt["total_ms"]
+    assert plan.minmax() == (float(img.min()), float(img.max()))
+
+
+def test_keypoints_integer_and_device_inputs(siftlib, oracle):
+    import sift_pyocl_amd as sp
+    import torch
+    img = (smooth_noise((200, 300)) * 60000).astype(np.uint16)
+    exp = oracle.keypoints(img.astype(np.float32))
+    plan = sp.SiftPlan(template=img)
+    assert_same_keypoints(plan.keypoints(img), exp, "uint16 input")
+    assert_same_keypoints(plan.keypoints(img.astype(np.float32)), exp, "float32 image on a uint16 plan")
+    t = torch.from_numpy(img.astype(np.float32)).cuda()
+    fplan = sp.SiftPlan(shape=img.shape, dtype=np.float32)
+    assert_same_keypoints(fplan.keypoints(t), exp, "device-resident torch input")
+
+
+def test_keypoints_errors(siftlib):
+    import sift_pyocl_amd as sp
+    with pytest.raises(RuntimeError):
+        sp.SiftPlan(shape=(4,), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        sp.SiftPlan(shape=(64, 64), dtype=np.complex64)
+    plan = sp.SiftPlan(shape=(64, 64), dtype=np.float32)
+    with pytest.raises(AssertionError):
+        plan.keypoints(np.zeros((32, 64), np.float32))
+    with pytest.raises(AssertionError):
+        plan.keypoints(np.zeros((64, 64), np.uint8))
+
+
+# ----------------------------------------------------------------------------- matching
+def _random_kp(n, seed):
+    rng = np.random.default_rng(seed)
+    from util import dtype_kp
+    k = np.zeros(n, dtype_kp)
+    k["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    k["x"] = rng.random(n); k["y"] = rng.random(n)
+    return k
+
+
+@pytest.mark.parametrize("n1,n2", [(1000, 1500), (1, 1), (3, 1), (513, 64), (2000, 2000)])
+def test_match_bit_exact(siftlib, oracle, n1, n2):
+    import sift_pyocl_amd as sp
+    a = _random_kp(n1, 1)
+    rng = np.random.default_rng(2)
+    b = _random_kp(n2, 3)
+    m = min(n1, n2) // 2
+    idx = rng.permutation(n1)[:m]
+    noisy = np.clip(a["desc"][idx].astype(int) + rng.integers(-8, 9, (m, 128)), 0, 255).astype(np.uint8)
+    b["desc"][:m] = noisy
+    if n2 > 4:
+        b["desc"][3] = b["desc"][2]          # exact duplicates: tie-break and dist2 == 0 paths
+    mp = sp.MatchPlan()
+    got = mp.match(a, b, raw_results=True)
+    exp, total = oracle.match(a, b)
+    assert len(got) == total
+    assert np.array_equal(sort_rows(got), sort_rows(exp))
+    rec = mp.match(a, b)
+    assert rec.shape == (len(got), 2) and rec.dtype == mp.dtype_kp
+
+
+def test_match_real_keypoints(siftlib, oracle):
+    import sift_pyocl_amd as sp
+    img = smooth_noise((400, 400))
+    shifted = np.roll(img, (5, 8), axis=(0, 1))
+    plan = sp.SiftPlan(template=img)
+    k1, k2 = plan.keypoints(img), plan.keypoints(shifted)
+    mp = sp.MatchPlan()
+    got = mp.match(k1, k2, raw_results=True)
+    exp, total = oracle.match(k1, k2)
+    assert total == len(got) and np.array_equal(sort_rows(got), sort_rows(exp))
+    pairs = mp.match(k1, k2)
+    assert np.median(pairs[:, 1].x - pairs[:, 0].x) == 8 and np.median(pairs[:, 1].y - pairs[:, 0].y) == 5

@@ -179,22 +179,49 @@ __global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, i
 }
 
 // ------------------------------------------------------------------------------------------
-// Descriptor: one single-wave workgroup per oriented keypoint (keypoints_cpu.cl:36-161).
-// LDS holds a 64 x 128 contribution table: row = sample lane of the current chunk, column = bin.
-// A sample touches at most 8 distinct bins, so each lane writes <= 8 cells; lane l then owns bins
-// 2l, 2l+1 and adds the table rows in ascending (raster) order; the other cells are exact +0.0f.
-__global__ __launch_bounds__(64) void descriptor_kernel(BlurPlanes b, int W, int H, int octsize,
-                                                        const float4 *__restrict__ okp,
-                                                        const int *__restrict__ oaux, const Counters *cnt,
-                                                        int range_start, int range_end,  // used when cnt == nullptr
-                                                        int out_capacity, KpRecord *__restrict__ records) {
-    __shared__ float T[64 * 128];
-    const int lane = threadIdx.x;
+// Descriptor: ONE WAVEFRONT per oriented keypoint, no workgroup barriers (keypoints_cpu.cl:36-161).
+//
+//  1. The (2R+1)^2 raster scan is filtered to the samples that fall inside the rotated 5x5-cell
+//     window by an ORDER-PRESERVING compaction (wave ballot + popcount prefix) into a small LDS
+//     list that also keeps the sample's (rx, cx).
+//  2. 64 listed samples at a time, every lane evaluates one sample (gradient, atan2, exp, the
+//     trilinear weights) and publishes in LDS its <= 8 contribution values, its packed cell origin
+//     (ri, ci, oi) and one bit per touched bin in that bin's 64-bit "who contributes" mask
+//     (LDS atomic OR: order independent).
+//  3. Lane l owns bins l and l+64: it walks the set bits of each mask in ascending order -- the raster
+//     order of the samples -- and adds the matching values one by one, so every bin sees exactly
+//     the reference's sequence of float additions.
+// Waves of a block are independent (4 keypoints per 256-thread block); latency is hidden by
+// occupancy instead of by barriers.
+#ifdef SIFT_ABLATE
+__device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/exp, 3 refill only
+#define ABL(x) (g_ablate == (x))
+#else
+#define ABL(x) false
+#endif
+
+struct DescWaveLds {
+    float cvals[8 * 64];          // [parity slot of the bin][sample lane]
+    unsigned int bmask[128 * 2];  // per bin: 64-bit mask of contributing lanes
+    int sij[128];                 // packed (ii + 32768) | (jj + 32768) << 16
+    float srx[128], scx[128];
+    float V[128];
+};
+
+__global__ __launch_bounds__(256) void descriptor_kernel(BlurPlanes b, int W, int H, int octsize,
+                                                         const float4 *__restrict__ okp,
+                                                         const int *__restrict__ oaux, const Counters *cnt,
+                                                         int range_start, int range_end,  // used when cnt == nullptr
+                                                         int out_capacity, KpRecord *__restrict__ records) {
+    __shared__ DescWaveLds lds_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    DescWaveLds &L = lds_all[wave];
     int start = range_start, end = range_end;
     if (cnt) { start = cnt->oct_start; end = min(cnt->n_out, out_capacity); }
-    for (int k = lane; k < 64 * 128; k += 64) T[k] = 0.0f;
-    __syncthreads();
-    for (int i = start + blockIdx.x; i < end; i += gridDim.x) {
+    for (int k = lane; k < 128 * 2; k += 64) L.bmask[k] = 0u;
+    const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int i = start + gwave; i < end; i += nwaves) {
         const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
         const int scale = oaux[i];
         KpRecord *rec = records + i;
@@ -215,29 +242,46 @@ __global__ __launch_bounds__(64) void descriptor_kernel(BlurPlanes b, int W, int
         const int S = 2 * iradius + 1;
         const int total = S * S;
         const float inv_S = 1.0f / (float)S;
-        float acc0 = 0.0f, acc1 = 0.0f;  // bins 2*lane, 2*lane+1
-        for (int base = 0; base < total; base += 64) {
-            const int idx = base + lane;
-            bool inside = false;
-            float rx = 0.f, cx = 0.f;
-            int yy = 0, xx = 0;
-            if (idx < total) {
-                int rem;
-                const int q = div_exact(idx, S, inv_S, rem);
-                const int ii = q - iradius, jj = rem - iradius;
-                rx = ((cosine * (float)ii - sine * (float)jj) - drow) / spacing + 1.5f;
-                cx = ((sine * (float)ii + cosine * (float)jj) - dcol) / spacing + 1.5f;
-                yy = irow + ii; xx = icol + jj;
-                inside = rx > -1.0f && rx < 4.0f && cx > -1.0f && cx < 4.0f && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float acc0 = 0.0f, acc1 = 0.0f;  // bins lane and lane + 64
+        int list_n = 0, pos = 0;
+        while (pos < total || list_n > 0) {
+            // ---- 1. refill the ordered list of in-window samples
+            while (list_n < 64 && pos < total) {
+                const int idx = pos + lane;
+                bool inside = false;
+                float rx = 0.f, cx = 0.f;
+                int ii = 0, jj = 0;
+                if (idx < total) {
+                    int rem;
+                    const int q = div_exact(idx, S, inv_S, rem);
+                    ii = q - iradius; jj = rem - iradius;
+                    rx = ((cosine * (float)ii - sine * (float)jj) - drow) / spacing + 1.5f;
+                    cx = ((sine * (float)ii + cosine * (float)jj) - dcol) / spacing + 1.5f;
+                    const int yy = irow + ii, xx = icol + jj;
+                    inside = rx > -1.0f && rx < 4.0f && cx > -1.0f && cx < 4.0f && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                }
+                const unsigned long long bal = __ballot(inside);
+                if (inside) {
+                    const int at = list_n + __popcll(bal & lt_mask);
+                    L.sij[at] = (ii + 32768) | ((jj + 32768) << 16);
+                    L.srx[at] = rx;
+                    L.scx[at] = cx;
+                }
+                list_n += __popcll(bal);
+                pos += 64;
             }
-            if (__ballot(inside) == 0) continue;
-            bool contributes = false;
-            int cell[8];
-            if (inside) {
+            __builtin_amdgcn_wave_barrier();
+            // ---- 2. evaluate up to 64 listed samples
+            const int m = min(list_n, 64);
+            if (lane < m && !ABL(3)) {
+                const int pk = L.sij[lane];
+                const int ii = (pk & 0xffff) - 32768, jj = ((pk >> 16) & 0xffff) - 32768;
+                const float rx = L.srx[lane], cx = L.scx[lane];
                 float g, o;
-                gradient_at(I, xx, yy, W, H, g, o);
+                if (ABL(2)) { g = I[(size_t)(irow + ii) * W + icol + jj]; o = g * 0.01f; }
+                else gradient_at(I, icol + jj, irow + ii, W, H, g, o);
                 const float er = rx - 1.5f, ec = cx - 1.5f;
-                const float mag = g * siftmath::expf_(-0.125f * (er * er + ec * ec));
+                const float mag = g * (ABL(2) ? (er * ec) : siftmath::expf_(-0.125f * (er * er + ec * ec)));
                 o = o - angle;
                 while (o > 2.0f * SM_PI_F) o -= 2.0f * SM_PI_F;
                 while (o < 0.0f) o += 2.0f * SM_PI_F;
@@ -246,8 +290,10 @@ __global__ __launch_bounds__(64) void descriptor_kernel(BlurPlanes b, int W, int
                 const int ci = (int)((cx >= 0.0f) ? cx : cx - 1.0f);
                 const int oi = (int)((oval >= 0.0f) ? oval : oval - 1.0f);
                 const float rf = rx - (float)ri, cf = cx - (float)ci, of = oval - (float)oi;
-                contributes = ri >= -1 && ri < 4 && oi >= 0 && oi <= 8 && rf >= 0.0f && rf <= 1.0f;
+                const bool contributes = ri >= -1 && ri < 4 && oi >= 0 && oi <= 8 && rf >= 0.0f && rf <= 1.0f;
                 if (contributes) {
+                    const unsigned int bit = 1u << (lane & 31);
+                    const int word = lane >> 5;
 #pragma unroll
                     for (int a = 0; a < 2; a++) {
                         const int rb = ri + a;
@@ -264,64 +310,83 @@ __global__ __launch_bounds__(64) void descriptor_kernel(BlurPlanes b, int W, int
                                 // e=0 adds cw*1 to bin 0, e=1 adds cw*0 == +0 (no effect) -> skipped.
                                 const bool dup = (e == 1 && oi == 8);
                                 if (ob >= 8) ob = 0;
-                                const int n8 = a * 4 + bb * 2 + e;
                                 if (ok && !dup) {
-                                    cell[n8] = lane * 128 + (rb * 4 + cb) * 8 + ob;
-                                    T[cell[n8]] = cw * (e == 0 ? 1.0f - of : of);
-                                } else cell[n8] = -1;
+                                    // the 8 bins of one sample differ in the parity of (rb, cb, ob): that
+                                    // parity is a slot index the bin owner can derive without knowing (ri,ci,oi)
+                                    L.cvals[((rb & 1) * 4 + (cb & 1) * 2 + (ob & 1)) * 64 + lane] = cw * (e == 0 ? 1.0f - of : of);
+                                    atomicOr(&L.bmask[((rb * 4 + cb) * 8 + ob) * 2 + word], bit);
+                                }
                             }
                         }
                     }
                 }
             }
-            __syncthreads();
-            uint64_t mask = __ballot(contributes);
-            while (mask) {
-                const int l = __ffsll((unsigned long long)mask) - 1;
-                mask &= mask - 1;
-                const float2 v = *reinterpret_cast<const float2 *>(&T[l * 128 + 2 * lane]);
-                acc0 = acc0 + v.x;
-                acc1 = acc1 + v.y;
-            }
-            __syncthreads();
-            if (contributes) {
+            __builtin_amdgcn_wave_barrier();
+            // ---- 3. ordered accumulation by the bin owners (lane owns bins lane, lane+64; both have
+            //         the same parity slot).  Four contributions per bin are fetched per step so the LDS
+            //         latency overlaps; exhausted masks add an exact +0.0f.
+            if (!(ABL(1) || ABL(3))) {
+                const float *vrow = &L.cvals[(((lane >> 5) & 1) * 4 + ((lane >> 3) & 1) * 2 + (lane & 1)) * 64];
+                const uint2 wa = *reinterpret_cast<const uint2 *>(&L.bmask[lane * 2]);
+                const uint2 wb = *reinterpret_cast<const uint2 *>(&L.bmask[(lane + 64) * 2]);
+                unsigned long long mka = (unsigned long long)wa.x | ((unsigned long long)wa.y << 32);
+                unsigned long long mkb = (unsigned long long)wb.x | ((unsigned long long)wb.y << 32);
+                if (mka) *reinterpret_cast<uint2 *>(&L.bmask[lane * 2]) = make_uint2(0u, 0u);
+                if (mkb) *reinterpret_cast<uint2 *>(&L.bmask[(lane + 64) * 2]) = make_uint2(0u, 0u);
+                while (mka | mkb) {
+                    float va[4], vb[4];
 #pragma unroll
-                for (int n8 = 0; n8 < 8; n8++) if (cell[n8] >= 0) T[cell[n8]] = 0.0f;
+                    for (int u = 0; u < 4; u++) {
+                        const bool oka = mka != 0, okb = mkb != 0;
+                        const int sa = oka ? __ffsll(mka) - 1 : 0, sb = okb ? __ffsll(mkb) - 1 : 0;
+                        mka &= mka - 1; mkb &= mkb - 1;
+                        const float ra = vrow[sa], rb_ = vrow[sb];
+                        va[u] = oka ? ra : 0.0f;
+                        vb[u] = okb ? rb_ : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { acc0 = acc0 + va[u]; acc1 = acc1 + vb[u]; }
+                }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+            // ---- drop the consumed entries, keep order
+            const int rest = list_n - m;
+            int mij = 0; float mrx = 0.f, mcx = 0.f;
+            if (lane < rest) { mij = L.sij[m + lane]; mrx = L.srx[m + lane]; mcx = L.scx[m + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) { L.sij[lane] = mij; L.srx[lane] = mrx; L.scx[lane] = mcx; }
+            list_n = rest;
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160).
         // The reference sums the 128 squares sequentially in index order: reproduce that order.
-        float *V = T;                    // row 0 of the table is free again
-        *reinterpret_cast<float2 *>(&V[2 * lane]) = make_float2(acc0, acc1);
-        __syncthreads();
+        L.V[lane] = acc0; L.V[lane + 64] = acc1;
+        __builtin_amdgcn_wave_barrier();
         float norm = 0.0f;
 #pragma unroll 8
-        for (int k2 = 0; k2 < 128; k2++) { const float t = V[k2]; norm = norm + t * t; }
+        for (int k2 = 0; k2 < 128; k2++) { const float t = L.V[k2]; norm = norm + t * t; }
         norm = 1.0f / sqrtf(norm);       // rsqrt
         acc0 = acc0 * norm; acc1 = acc1 * norm;
         const bool ch = (acc0 > 0.2f) || (acc1 > 0.2f);
         if (acc0 > 0.2f) acc0 = 0.2f;
         if (acc1 > 0.2f) acc1 = 0.2f;
-        __syncthreads();
-        *reinterpret_cast<float2 *>(&V[2 * lane]) = make_float2(acc0, acc1);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        L.V[lane] = acc0; L.V[lane + 64] = acc1;
+        __builtin_amdgcn_wave_barrier();
         if (__ballot(ch)) {
             float n2 = 0.0f;
 #pragma unroll 8
-            for (int k2 = 0; k2 < 128; k2++) { const float t = V[k2]; n2 = n2 + t * t; }
+            for (int k2 = 0; k2 < 128; k2++) { const float t = L.V[k2]; n2 = n2 + t * t; }
             n2 = 1.0f / sqrtf(n2);
             acc0 = acc0 * n2; acc1 = acc1 * n2;
         }
-        __syncthreads();
-        *reinterpret_cast<float2 *>(&V[2 * lane]) = make_float2(0.f, 0.f);   // table back to all zero
+        __builtin_amdgcn_wave_barrier();
         // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see oracle note)
         const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
-        const uint32_t b0 = (uint32_t)min(255, i0) & 0xffu, b1 = (uint32_t)min(255, i1) & 0xffu;
+        rec->desc[lane] = (uint8_t)min(255, i0);
+        rec->desc[lane + 64] = (uint8_t)min(255, i1);
         if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
-        reinterpret_cast<uint16_t *>(rec->desc)[lane] = (uint16_t)(b0 | (b1 << 8));
-        __syncthreads();
     }
 }
 

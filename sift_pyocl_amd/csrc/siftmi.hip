@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -260,7 +261,7 @@ void launch_detect_octave(siftmi_plan *p, int oct) {
     {
         snprintf(lab, sizeof lab, "descriptors %d", oct);
         Scope sc(p, lab);
-        hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(64), 0, p->stream, bp, W, H, octsize,
+        hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(256), 0, p->stream, bp, W, H, octsize,
                            (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, 0, 0, kcap, p->records);
     }
 }
@@ -272,6 +273,14 @@ extern "C" {
 
 const char *siftmi_last_error(void) { return g_err.c_str(); }
 const char *siftmi_version(void) { return "sift_pyocl_amd 0.1 (gfx950)"; }
+
+#ifdef SIFT_ABLATE
+static void apply_ablate() {
+    const char *e = getenv("SIFTMI_ABLATE");
+    int v = e ? atoi(e) : 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(siftk::g_ablate), &v, sizeof v);
+}
+#endif
 
 int siftmi_device_count(void) {
     int n = 0;
@@ -388,6 +397,9 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         src = p->raw;
     }
     p->n_events = 0;
+#ifdef SIFT_ABLATE
+    apply_ablate();
+#endif
     if (p->profile) hipEventRecord(p->ev_first, p->stream);
     hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt);
     const float *f32src = (const float *)src;
@@ -827,7 +839,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
     BlurPlanes bp;
     for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
     if (n > 0)
-        hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(64), 0, 0, bp, W, H, octsize,
+        hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(256), 0, 0, bp, W, H, octsize,
                            (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, (int)n,
                            (int)n, r.as<KpRecord>());
     if ((rc = stage_end())) return rc;

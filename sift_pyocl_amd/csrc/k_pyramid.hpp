@@ -193,6 +193,204 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused separable blur, "marching" form, for large planes.
+//
+// A 128-thread workgroup (2 waves) owns a strip 256 columns wide and marches down `nblocks`
+// blocks of N rows:
+//   * the next block's N x (256+N-1) inputs are prefetched into registers while the current block
+//     is processed, then staged in LDS with the rows interleaved in pairs ([row pair][col][row&1]),
+//   * horizontal pass in place in LDS: a lane owns 4 consecutive outputs of a ROW PAIR and slides
+//     over N+3 float2 inputs (ds_read_b128); the two rows ride in the two halves of packed-f32
+//     instructions (v_pk_mul_f32 / v_pk_add_f32, measured 1.5x the rate of scalar mul+add),
+//   * vertical pass without a window: thread t owns columns 2t, 2t+1 (one packed pair) and keeps
+//     the N in-flight output rows as N rotating packed accumulators.  Row k adds h*taps[N-1-j] to
+//     the accumulator of output row k-j (j = 0..N-1); rows arrive in ascending order, so every
+//     output receives its taps in exactly the reference's order (j ascending, starting from 0.0f).
+//     The taps are bitwise symmetric (taps[j] == taps[N-1-j], checked on the host), so only
+//     (N+1)/2 distinct products per row are formed; each is the same IEEE product the reference
+//     computes.  With the march unrolled N times every accumulator index is a compile-time constant.
+// No FMA anywhere: the pyramid is bit-identical to the reference's unfused arithmetic.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N> struct MarchGeom {
+    static constexpr int TX = 256;
+    static constexpr int C = (N & 1) ? N / 2 : N / 2 - 1;
+    static constexpr int NP = (N + 1) / 2;                   // row pairs per block
+    static constexpr int COLS = TX + N - 1;
+    static constexpr int PITCH = (COLS + 3) & ~3;            // columns per row pair
+    static constexpr int NW = (N + 3 + 1) & ~1;              // columns read per 4-output H task (even)
+    static constexpr int LDS_BYTES = NP * PITCH * 2 * 4;
+    static constexpr int HALO = N - 1;                       // columns beyond the first 256
+    static constexpr int NB = (NP * HALO + 127) / 128;       // halo pair-elements per thread
+};
+
+template <int N, bool NORM>
+__global__ __launch_bounds__(128) void blur_march_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                         int W, int H, int nblocks, TapsArg<N> taps,
+                                                         const uint32_t *__restrict__ mm) {
+    using G = MarchGeom<N>;
+    static_assert(N & 1, "marching blur needs an odd tap count");
+    extern __shared__ float4 smem4[];
+    float *s = reinterpret_cast<float *>(smem4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * G::TX;
+    const int rows_out = nblocks * N - (N - 1);
+    const int ys = blockIdx.y * rows_out;            // first output row of this segment
+    const int yend = min(ys + rows_out, H);
+    float mn = 0.f, range = 1.f;
+    if (NORM) { mn = ord2f(mm[0]); range = ord2f(mm[1]) - mn; }
+
+    // staging duty of this thread: columns tid and tid+128 of every row, plus NB halo pair-elements
+    const int gx_a = reflect_index(x0 - G::C + tid, W);
+    const int gx_b = reflect_index(x0 - G::C + 128 + tid, W);
+    int hb_rp[G::NB], hb_col[G::NB], hb_gx[G::NB];
+#pragma unroll
+    for (int u = 0; u < G::NB; u++) {
+        const int e = tid + 128 * u;
+        hb_rp[u] = (e < G::NP * G::HALO) ? e / G::HALO : -1;
+        hb_col[u] = 256 + e % G::HALO;
+        hb_gx[u] = reflect_index(x0 - G::C + hb_col[u], W);
+    }
+
+    // 32-bit byte offsets from the (scalar) plane base keep each load's address in one VGPR
+    auto ld = [&](unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + byte_off); };
+    const unsigned W4 = (unsigned)W * 4u;
+    auto norm2 = [&](f32x2 v) {
+        if (NORM) { v.x = 255.0f * (v.x - mn) / range; v.y = 255.0f * (v.y - mn) / range; }   // preprocess.cl:250
+        return v;
+    };
+
+    f32x2 acc[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = (f32x2){0.f, 0.f};
+    const int gxo = x0 + 2 * tid;                     // first of the two output columns
+    const bool vec_store = ((W & 1) == 0) && (gxo + 1 < W);
+
+    // register look-ahead: the next block's inputs are fetched while the current block is filtered
+    f32x2 pa[G::NP], pb[G::NP], ph[G::NB];
+    auto prefetch = [&](int blk) {
+        const int v0 = ys - G::C + blk * N;
+        if (v0 >= 0 && v0 + N + 1 <= H) {             // interior rows: walk per-thread offsets
+            unsigned oa = ((unsigned)v0 * (unsigned)W + (unsigned)gx_a) * 4u;
+            unsigned ob = ((unsigned)v0 * (unsigned)W + (unsigned)gx_b) * 4u;
+#pragma unroll
+            for (int rp = 0; rp < G::NP; rp++) {
+                pa[rp].x = ld(oa); pa[rp].y = ld(oa + W4);
+                pb[rp].x = ld(ob); pb[rp].y = ld(ob + W4);
+                oa += 2u * W4; ob += 2u * W4;
+            }
+        } else {
+#pragma unroll
+            for (int rp = 0; rp < G::NP; rp++) {
+                const unsigned r0 = (unsigned)reflect_index(v0 + 2 * rp, H) * W4, r1 = (unsigned)reflect_index(v0 + 2 * rp + 1, H) * W4;
+                pa[rp].x = ld(r0 + 4u * gx_a); pa[rp].y = ld(r1 + 4u * gx_a);
+                pb[rp].x = ld(r0 + 4u * gx_b); pb[rp].y = ld(r1 + 4u * gx_b);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G::NB; u++) {
+            ph[u] = (f32x2){0.f, 0.f};
+            if (hb_rp[u] >= 0) {
+                ph[u].x = ld((unsigned)reflect_index(v0 + 2 * hb_rp[u], H) * W4 + 4u * hb_gx[u]);
+                ph[u].y = ld((unsigned)reflect_index(v0 + 2 * hb_rp[u] + 1, H) * W4 + 4u * hb_gx[u]);
+            }
+        }
+    };
+    prefetch(0);
+
+    for (int blk = 0; blk < nblocks; blk++) {
+        __syncthreads();                              // previous block's vertical reads are done
+        // ---- stage the prefetched rows as [row pair][column][row & 1]
+#pragma unroll
+        for (int rp = 0; rp < G::NP; rp++) {
+            *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + tid) * 2) = norm2(pa[rp]);
+            *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + 128 + tid) * 2) = norm2(pb[rp]);
+        }
+#pragma unroll
+        for (int u = 0; u < G::NB; u++)
+            if (hb_rp[u] >= 0) *reinterpret_cast<f32x2 *>(s + (hb_rp[u] * G::PITCH + hb_col[u]) * 2) = norm2(ph[u]);
+        __syncthreads();
+        if (blk + 1 < nblocks) prefetch(blk + 1);
+        // ---- horizontal pass in place: wave w takes row pairs w, w+2, ...; lane owns 4 columns
+        for (int rp = wave; rp < G::NP; rp += 2) {
+            float *rowp = s + (rp * G::PITCH + 4 * lane) * 2;
+            // sliding window streamed through registers: b128 loads run PRE ahead of their first use
+            f32x2 w[G::NW];
+            constexpr int PRE = 4;
+#pragma unroll
+            for (int k = 0; k < PRE && k < G::NW / 2; k++) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
+                w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
+            }
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                if ((q & 1) == 0) {
+                    const int k = q / 2 + PRE;
+                    if (k < G::NW / 2) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
+                        w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float tp = taps.t[N - 1 - q];
+                const f32x2 tp2 = {tp, tp};
+                a0 = a0 + w[q] * tp2;
+                a1 = a1 + w[q + 1] * tp2;
+                a2 = a2 + w[q + 2] * tp2;
+                a3 = a3 + w[q + 3] * tp2;
+            }
+            __builtin_amdgcn_wave_barrier();          // the whole row pair lives in this wave: reads precede stores
+            // result layout for the vertical pass: [row pair][column pair][row & 1][column & 1]
+            *reinterpret_cast<f32x4 *>(rowp) = (f32x4){a0.x, a1.x, a0.y, a1.y};
+            *reinterpret_cast<f32x4 *>(rowp + 4) = (f32x4){a2.x, a3.x, a2.y, a3.y};
+        }
+        __syncthreads();
+        // ---- vertical march over the N rows of this block (fully unrolled: static accumulator slots)
+        const int ybase = ys + blk * N - (N - 1);     // output row completed by step kk is ybase + kk
+        float *optr = out + ((ptrdiff_t)ybase * W + gxo);   // only dereferenced for valid rows
+        f32x4 hv_next = *reinterpret_cast<const f32x4 *>(s + (2 * tid) * 2);
+#pragma unroll
+        for (int rp = 0; rp < G::NP; rp++) {
+            const f32x4 hv = hv_next;                 // LDS read issued one row pair ahead
+            if (rp + 1 < G::NP) hv_next = *reinterpret_cast<const f32x4 *>(s + ((rp + 1) * G::PITCH + 2 * tid) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int kk = 2 * rp + half;
+                if (kk < N) {
+                    const f32x2 h = half ? hv.zw : hv.xy;
+                    f32x2 prod[(N + 1) / 2];
+#pragma unroll
+                    for (int k = 0; k < (N + 1) / 2; k++) { const f32x2 t2 = {taps.t[k], taps.t[k]}; prod[k] = h * t2; }
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        const int slot = (kk - j + N) % N;
+                        const int k = (j < N - 1 - j) ? j : N - 1 - j;   // taps[N-1-j] == taps[j] bitwise
+                        if (j == 0) acc[slot] = (f32x2){0.f, 0.f} + prod[k];
+                        else acc[slot] = acc[slot] + prod[k];
+                        // Pin the addition here: otherwise the compiler sinks each output's whole
+                        // add chain into its (conditional) store and keeps every product alive.
+                        asm volatile("" : "+v"(acc[slot]));
+                    }
+                    const int done = (kk + 1) % N;    // the output whose last tap (j = N-1) was just added
+                    const int y = ybase + kk;
+                    if (y >= ys && y < yend) {
+                        if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];
+                        else {
+                            if (gxo < W) optr[0] = acc[done].x;
+                            if (gxo + 1 < W) optr[1] = acc[done].y;
+                        }
+                    }
+                    optr += W;
+                }
+            }
+        }
+    }
+}
+
 // Generic (any tap count, incl. even sizes) two-pass blur: plain global loads, used only for
 // non-default init_sigma schedules and stage replay.  Same arithmetic.
 __global__ void blur_generic_pass(const float *__restrict__ in, float *__restrict__ out, int W, int H,

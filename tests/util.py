@@ -55,3 +55,32 @@ def assert_same_keypoints(a, b, what=""):
 def sort_rows(a):
     a = np.asarray(a)
     return a[np.lexsort(a.T[::-1])]
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, np.int64(-2 ** 31) - a, a)
+    b = np.where(b < 0, np.int64(-2 ** 31) - b, b)
+    return np.abs(a - b)
+
+
+def compare_keypoints_libm(a, b, what="", ulp=2, max_bad_rows=0.01):
+    """Comparison against the glibc-backed native build of the reference kernels.  x and y (pure
+    +,*,/ arithmetic) must be bit-identical; scale (pow) and angle (atan2/exp chain) may differ by
+    `ulp` units in the last place because glibc 2.35's powf/atan2f are not correctly rounded while
+    the oracle's are; descriptor bins may then differ by 1 LSB in at most `max_bad_rows` of the rows.
+    Returns a dict of the measured differences."""
+    assert len(a) == len(b), "%s: %d vs %d keypoints" % (what, len(a), len(b))
+    a, b = sort_kp(a), sort_kp(b)
+    assert np.array_equal(a["x"].view(np.uint32), b["x"].view(np.uint32)), what + ": x differs"
+    assert np.array_equal(a["y"].view(np.uint32), b["y"].view(np.uint32)), what + ": y differs"
+    ds, da = ulp_diff(a["scale"], b["scale"]), ulp_diff(a["angle"], b["angle"])
+    assert ds.max(initial=0) <= ulp, "%s: scale differs by %d ulp" % (what, ds.max())
+    assert da.max(initial=0) <= ulp, "%s: angle differs by %d ulp" % (what, da.max())
+    dd = np.abs(a["desc"].astype(np.int16) - b["desc"].astype(np.int16))
+    assert dd.max(initial=0) <= 1, "%s: descriptor bins differ by %d" % (what, dd.max())
+    bad = int(((ds > 0) | (da > 0) | (dd.max(axis=1) > 0)).sum()) if len(a) else 0
+    assert bad <= max(2, max_bad_rows * len(a)), "%s: %d of %d rows differ" % (what, bad, len(a))
+    return dict(rows=len(a), rows_differing=bad, scale_ulp=int(ds.max(initial=0)), angle_ulp=int(da.max(initial=0)),
+                desc_bins_differing=int((dd > 0).sum()))

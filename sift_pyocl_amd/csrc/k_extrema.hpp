@@ -44,11 +44,21 @@ __global__ __launch_bounds__(256) void extrema_kernel(BlurPlanes b, int W, int H
 #pragma unroll
         for (int k = 0; k < 3; k++) { hM[r][k] = 0.f; hm[r][k] = 0.f; }
 
+    float vn[6];                                     // next row's samples, loaded one iteration ahead
+    {
+        const size_t pos0 = (size_t)(ya - 1) * W + xc;
+#pragma unroll
+        for (int k = 0; k < 6; k++) vn[k] = b.p[k][pos0];
+    }
     for (int y = ya - 1; y <= yb; y++) {
-        const size_t pos = (size_t)y * W + xc;
         float v[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) v[k] = b.p[k][pos];
+        for (int k = 0; k < 6; k++) v[k] = vn[k];
+        if (y < yb) {
+            const size_t posn = (size_t)(y + 1) * W + xc;
+#pragma unroll
+            for (int k = 0; k < 6; k++) vn[k] = b.p[k][posn];
+        }
         float d[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) d[k] = v[k] - v[k + 1];
@@ -109,8 +119,14 @@ __global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H,
                                                      const int *__restrict__ n_cand, int cand_capacity,
                                                      float peak_thresh, float init_sigma,
                                                      float4 *__restrict__ kp, int *__restrict__ kp_scale,
-                                                     int *__restrict__ n_kp, int kp_capacity) {
+                                                     int *__restrict__ n_kp, int kp_capacity,
+                                                     const int *__restrict__ n_out, int *__restrict__ oct_start,
+                                                     int *__restrict__ overflow) {
     const int n = min(*n_cand, cand_capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (oct_start) *oct_start = *n_out;          // first record index of this octave
+        if (*n_cand > cand_capacity && overflow) *overflow = 1;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 k = cand[i];
         int r = (int)k.y, c = (int)k.z;

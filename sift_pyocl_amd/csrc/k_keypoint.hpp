@@ -45,21 +45,23 @@ __device__ __forceinline__ int div_exact(int idx, int d, float inv, int &rem) {
     return q;
 }
 
-// device counters shared by the per-octave kernels
+// device counters.  Per-octave slots are zeroed once per image, so no kernel has to reset anything
+// between octaves; oct_start[o] is recorded by the refine kernel of octave o (stream order puts it
+// after the descriptor kernel of octave o-1 and before the orientation kernel of octave o).
+#define SIFT_MAX_OCTAVES 24
 struct Counters {
-    int n_cand;      // candidates of the current octave
-    int n_kp;        // refined keypoints of the current octave
-    int n_out;       // oriented keypoints, all octaves so far (index into the record list)
-    int oct_start;   // n_out at the start of the current octave
-    int overflow;    // set when a list hit its capacity
-    int pad[3];
+    int n_out;                          // oriented keypoints, all octaves so far (index into the record list)
+    int overflow;                       // set when a list hit its capacity
+    int pad[2];
+    int n_cand[SIFT_MAX_OCTAVES];       // candidates per octave
+    int n_kp[SIFT_MAX_OCTAVES];         // refined keypoints per octave
+    int oct_start[SIFT_MAX_OCTAVES];    // n_out at the start of each octave
 };
 
-__global__ void begin_octave_kernel(Counters *c) { c->n_cand = 0; c->n_kp = 0; c->oct_start = c->n_out; }
-__global__ void begin_image_kernel(Counters *c) { c->n_cand = 0; c->n_kp = 0; c->n_out = 0; c->oct_start = 0; c->overflow = 0; }
-__global__ void clamp_counts_kernel(Counters *c, int cand_cap, int kp_cap) {
-    if (c->n_cand > cand_cap) { c->n_cand = cand_cap; c->overflow = 1; }
-    if (c->n_kp > kp_cap) { c->n_kp = kp_cap; c->overflow = 1; }
+__global__ void begin_image_kernel(Counters *c) {
+    const int t = threadIdx.x;
+    if (t == 0) { c->n_out = 0; c->overflow = 0; }
+    if (t < SIFT_MAX_OCTAVES) { c->n_cand[t] = 0; c->n_kp[t] = 0; c->oct_start[t] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -67,15 +69,16 @@ __global__ void clamp_counts_kernel(Counters *c, int cand_cap, int kp_cap) {
 // Output goes straight to the image-wide oriented list (x, y, sigma*oct, angle) + detection scale.
 __global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, int H, int octsize, float ori_sigma,
                                                           const float4 *__restrict__ kp,
-                                                          const int *__restrict__ kp_scale, Counters *cnt,
+                                                          const int *__restrict__ kp_scale, Counters *cnt, int oct,
                                                           int kp_capacity, float4 *__restrict__ okp,
                                                           int *__restrict__ oaux, int out_capacity,
                                                           int per_octave_capacity) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int n = min(cnt->n_kp, kp_capacity);
-    const int oct_start = cnt->oct_start;
+    const int n = min(cnt->n_kp[oct], kp_capacity);
+    if (cnt->n_kp[oct] > kp_capacity && threadIdx.x == 0 && blockIdx.x == 0) cnt->overflow = 1;
+    const int oct_start = cnt->oct_start[oct];
     for (int i = wave; i < n; i += nwaves) {
         const float4 k = kp[i];          // (peak, row, col, sigma)
         const int scale = kp_scale[i];
@@ -201,8 +204,9 @@ __device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/
 #endif
 
 struct DescWaveLds {
-    float cvals[8 * 64];          // [parity slot of the bin][sample lane]
-    unsigned int bmask[128 * 2];  // per bin: 64-bit mask of contributing lanes
+    uint4 binfo[128];             // per bin: {mask lo, mask hi, pool base, -} : 64-bit mask of contributing lanes
+    float pool[8 * 64];           // contribution values, grouped by bin, in lane (= raster) order inside a bin
+    int pool_cnt;
     int sij[128];                 // packed (ii + 32768) | (jj + 32768) << 16
     float srx[128], scx[128];
     float V[128];
@@ -210,15 +214,16 @@ struct DescWaveLds {
 
 __global__ __launch_bounds__(256) void descriptor_kernel(BlurPlanes b, int W, int H, int octsize,
                                                          const float4 *__restrict__ okp,
-                                                         const int *__restrict__ oaux, const Counters *cnt,
+                                                         const int *__restrict__ oaux, const Counters *cnt, int oct,
                                                          int range_start, int range_end,  // used when cnt == nullptr
                                                          int out_capacity, KpRecord *__restrict__ records) {
     __shared__ DescWaveLds lds_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescWaveLds &L = lds_all[wave];
     int start = range_start, end = range_end;
-    if (cnt) { start = cnt->oct_start; end = min(cnt->n_out, out_capacity); }
-    for (int k = lane; k < 128 * 2; k += 64) L.bmask[k] = 0u;
+    if (cnt) { start = cnt->oct_start[oct]; end = min(cnt->n_out, out_capacity); }
+    L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u); L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) L.pool_cnt = 0;
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int i = start + gwave; i < end; i += nwaves) {
@@ -273,6 +278,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(BlurPlanes b, int W, in
             __builtin_amdgcn_wave_barrier();
             // ---- 2. evaluate up to 64 listed samples
             const int m = min(list_n, 64);
+            int cbin[8];
+            float cval[8];
+#pragma unroll
+            for (int n8 = 0; n8 < 8; n8++) { cbin[n8] = -1; cval[n8] = 0.0f; }
             if (lane < m && !ABL(3)) {
                 const int pk = L.sij[lane];
                 const int ii = (pk & 0xffff) - 32768, jj = ((pk >> 16) & 0xffff) - 32768;
@@ -310,11 +319,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(BlurPlanes b, int W, in
                                 // e=0 adds cw*1 to bin 0, e=1 adds cw*0 == +0 (no effect) -> skipped.
                                 const bool dup = (e == 1 && oi == 8);
                                 if (ob >= 8) ob = 0;
+                                const int n8 = a * 4 + bb * 2 + e;
                                 if (ok && !dup) {
-                                    // the 8 bins of one sample differ in the parity of (rb, cb, ob): that
-                                    // parity is a slot index the bin owner can derive without knowing (ri,ci,oi)
-                                    L.cvals[((rb & 1) * 4 + (cb & 1) * 2 + (ob & 1)) * 64 + lane] = cw * (e == 0 ? 1.0f - of : of);
-                                    atomicOr(&L.bmask[((rb * 4 + cb) * 8 + ob) * 2 + word], bit);
+                                    cbin[n8] = (rb * 4 + cb) * 8 + ob;
+                                    cval[n8] = cw * (e == 0 ? 1.0f - of : of);
+                                    atomicOr(reinterpret_cast<unsigned int *>(&L.binfo[cbin[n8]]) + word, bit);
                                 }
                             }
                         }
@@ -322,31 +331,46 @@ __global__ __launch_bounds__(256) void descriptor_kernel(BlurPlanes b, int W, in
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- 3. ordered accumulation by the bin owners (lane owns bins lane, lane+64; both have
-            //         the same parity slot).  Four contributions per bin are fetched per step so the LDS
-            //         latency overlaps; exhausted masks add an exact +0.0f.
+            // ---- 3. ordered accumulation.  (a) every bin owner (lane owns bins lane, lane+64) reserves a
+            //         pool segment for its contributors; (b) every sample lane writes each of its values at
+            //         segment base + (number of lower lanes contributing to the same bin); (c) the owner adds
+            //         its segment front to back: ascending lane == raster order of the samples.
             if (!(ABL(1) || ABL(3))) {
-                const float *vrow = &L.cvals[(((lane >> 5) & 1) * 4 + ((lane >> 3) & 1) * 2 + (lane & 1)) * 64];
-                const uint2 wa = *reinterpret_cast<const uint2 *>(&L.bmask[lane * 2]);
-                const uint2 wb = *reinterpret_cast<const uint2 *>(&L.bmask[(lane + 64) * 2]);
-                unsigned long long mka = (unsigned long long)wa.x | ((unsigned long long)wa.y << 32);
-                unsigned long long mkb = (unsigned long long)wb.x | ((unsigned long long)wb.y << 32);
-                if (mka) *reinterpret_cast<uint2 *>(&L.bmask[lane * 2]) = make_uint2(0u, 0u);
-                if (mkb) *reinterpret_cast<uint2 *>(&L.bmask[(lane + 64) * 2]) = make_uint2(0u, 0u);
-                while (mka | mkb) {
+                uint4 ia = L.binfo[lane], ib = L.binfo[lane + 64];
+                const int cnta = __popc(ia.x) + __popc(ia.y), cntb = __popc(ib.x) + __popc(ib.y);
+                int base_a = 0;
+                if (cnta + cntb) base_a = atomicAdd(&L.pool_cnt, cnta + cntb);
+                const int base_b = base_a + cnta;
+                if (cnta) L.binfo[lane].z = (unsigned)base_a;
+                if (cntb) L.binfo[lane + 64].z = (unsigned)base_b;
+                __builtin_amdgcn_wave_barrier();
+                const unsigned lo_mask = (lane < 32) ? ((1u << lane) - 1u) : 0xffffffffu;
+                const unsigned hi_mask = (lane < 32) ? 0u : ((1u << (lane - 32)) - 1u);
+#pragma unroll
+                for (int n8 = 0; n8 < 8; n8++)
+                    if (cbin[n8] >= 0) {
+                        const uint4 bi = L.binfo[cbin[n8]];
+                        L.pool[bi.z + __popc(bi.x & lo_mask) + __popc(bi.y & hi_mask)] = cval[n8];
+                    }
+                __builtin_amdgcn_wave_barrier();
+                const int nmax = max(cnta, cntb);
+                for (int r0 = 0; r0 < nmax; r0 += 4) {
                     float va[4], vb[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const bool oka = mka != 0, okb = mkb != 0;
-                        const int sa = oka ? __ffsll(mka) - 1 : 0, sb = okb ? __ffsll(mkb) - 1 : 0;
-                        mka &= mka - 1; mkb &= mkb - 1;
-                        const float ra = vrow[sa], rb_ = vrow[sb];
-                        va[u] = oka ? ra : 0.0f;
-                        vb[u] = okb ? rb_ : 0.0f;
+                        const float ra = L.pool[(base_a + r0 + u) & 511], rb_ = L.pool[(base_b + r0 + u) & 511];
+                        va[u] = (r0 + u < cnta) ? ra : 0.0f;
+                        vb[u] = (r0 + u < cntb) ? rb_ : 0.0f;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) { acc0 = acc0 + va[u]; acc1 = acc1 + vb[u]; }
                 }
+                __builtin_amdgcn_wave_barrier();
+                if (cnta) L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u);
+                if (cntb) L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+                if (lane == 0) L.pool_cnt = 0;
+            } else {
+                L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u); L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
             }
             __builtin_amdgcn_wave_barrier();
             // ---- drop the consumed entries, keep order

@@ -31,13 +31,21 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ i
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n4 = n >> 2;
     const float4 *img4 = reinterpret_cast<const float4 *>(img);
-    for (int64_t k = i; k < n4; k += stride) {
+    int64_t k = i;
+    for (; k + 3 * stride < n4; k += 4 * stride) {    // four independent 16-byte loads in flight per lane
+        const float4 v0 = img4[k], v1 = img4[k + stride], v2 = img4[k + 2 * stride], v3 = img4[k + 3 * stride];
+        lo = fminf(lo, fminf(fminf(fminf(v0.x, v0.y), fminf(v0.z, v0.w)), fminf(fminf(v1.x, v1.y), fminf(v1.z, v1.w))));
+        lo = fminf(lo, fminf(fminf(fminf(v2.x, v2.y), fminf(v2.z, v2.w)), fminf(fminf(v3.x, v3.y), fminf(v3.z, v3.w))));
+        hi = fmaxf(hi, fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w))));
+        hi = fmaxf(hi, fmaxf(fmaxf(fmaxf(v2.x, v2.y), fmaxf(v2.z, v2.w)), fmaxf(fmaxf(v3.x, v3.y), fmaxf(v3.z, v3.w))));
+    }
+    for (; k < n4; k += stride) {
         float4 v = img4[k];
         lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
         hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
     }
-    for (int64_t k = (n4 << 2) + i; k < n; k += stride) {
-        float v = img[k];
+    for (int64_t k2 = (n4 << 2) + i; k2 < n; k2 += stride) {
+        float v = img[k2];
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
     }

@@ -270,28 +270,27 @@ void launch_detect_octave(siftmi_plan *p, int oct) {
         snprintf(lab, sizeof lab, "local_maxmin %d", oct);
         Scope sc(p, lab);
         hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, p->stream, bp, W, H, border,
-                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand, kcap);
+                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap);
     }
     {
         snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
         Scope sc(p, lab);
-        hipLaunchKernelGGL(clamp_counts_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt, kcap, kcap);
         hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, p->stream, bp, W, H, (const float4 *)p->cand,
-                           (const int *)&p->cnt->n_cand, kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
-                           p->kp_scale, &p->cnt->n_kp, kcap);
-        hipLaunchKernelGGL(clamp_counts_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt, kcap, kcap);
+                           (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
+                           p->kp_scale, &p->cnt->n_kp[oct], kcap, (const int *)&p->cnt->n_out, &p->cnt->oct_start[oct],
+                           &p->cnt->overflow);
     }
     {
         snprintf(lab, sizeof lab, "orientation_assignment %d", oct);
         Scope sc(p, lab);
         hipLaunchKernelGGL(orientation_kernel, dim3(1024), dim3(256), 0, p->stream, bp, W, H, octsize, p->par.ori_sigma,
-                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, kcap, p->okp, p->oaux, kcap, kcap);
+                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, oct, kcap, p->okp, p->oaux, kcap, kcap);
     }
     {
         snprintf(lab, sizeof lab, "descriptors %d", oct);
         Scope sc(p, lab);
         hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(256), 0, p->stream, bp, W, H, octsize,
-                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, 0, 0, kcap, p->records);
+                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, oct, 0, 0, kcap, p->records);
     }
 }
 
@@ -349,6 +348,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
         p->oh = hh; p->ow = ww;
         p->n_oct = (int)hh.size();
         if (params->octave_max > 0 && params->octave_max < p->n_oct) p->n_oct = params->octave_max;
+        if (p->n_oct > SIFT_MAX_OCTAVES) p->n_oct = SIFT_MAX_OCTAVES;
     }
     const size_t N = (size_t)height * width;
     p->kpsize = (int64_t)(N / (size_t)params->pix_per_kp);   // plan.py:243
@@ -430,7 +430,7 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     apply_ablate();
 #endif
     if (p->profile) hipEventRecord(p->ev_first, p->stream);
-    hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt);
+    hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt);
     const float *f32src = (const float *)src;
     if (image_dtype != SIFTMI_F32) {
         Scope sc(p, "convert -> float");
@@ -465,7 +465,6 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     char lab[96];
     for (int oct = 0; oct < p->n_oct; oct++) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
-        hipLaunchKernelGGL(begin_octave_kernel, dim3(1), dim3(1), 0, p->stream, p->cnt);
         for (int s = 0; s < 5; s++) {
             snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
             Scope sc(p, lab, true, (double)W * H);
@@ -778,12 +777,12 @@ int siftmi_stage_local_maxmin(int32_t dev, const float *blurs, int32_t W, int32_
         const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
         const float edth = (octsize <= 1) ? par->edge_thresh0 : par->edge_thresh;
         hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border,
-                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand, (int)capacity);
+                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity);
     }
     if ((rc = stage_end())) return rc;
     Counters hc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
-    int64_t n = hc.n_cand < capacity ? hc.n_cand : capacity;
+    int64_t n = hc.n_cand[0] < capacity ? hc.n_cand[0] : capacity;
     if (n > 0) HIPCHK(hipMemcpy(out, c.p, (size_t)n * 16, hipMemcpyDeviceToHost));
     *n_out = n;
     return SIFTMI_OK;
@@ -798,17 +797,17 @@ int siftmi_stage_interp(int32_t dev, const float *blurs, int32_t W, int32_t H, c
     if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = c.upload(cand, (size_t)n * 16)) || (rc = k.alloc((size_t)n * 16)) ||
         (rc = ks.alloc((size_t)n * 4)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
     Counters hc{};
-    hc.n_cand = (int)n;
+    hc.n_cand[0] = (int)n;
     HIPCHK(hipMemcpy(cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice));
     BlurPlanes bp;
     for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
     Counters *dc = cnt.as<Counters>();
     hipLaunchKernelGGL(refine_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, 0, bp, W, H, (const float4 *)c.as<float4>(),
-                       (const int *)&dc->n_cand, (int)n, par->peak_thresh, (float)par->init_sigma, k.as<float4>(),
-                       ks.as<int>(), &dc->n_kp, (int)n);
+                       (const int *)&dc->n_cand[0], (int)n, par->peak_thresh, (float)par->init_sigma, k.as<float4>(),
+                       ks.as<int>(), &dc->n_kp[0], (int)n, (const int *)nullptr, (int *)nullptr, (int *)nullptr);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
-    const int64_t m = hc.n_kp;
+    const int64_t m = hc.n_kp[0];
     if (m > 0) {
         HIPCHK(hipMemcpy(out, k.p, (size_t)m * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out_scale, ks.p, (size_t)m * 4, hipMemcpyDeviceToHost));
@@ -840,12 +839,12 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = k.upload(kps, (size_t)n * 16)) || (rc = ks.upload(kp_scale, (size_t)n * 4)) ||
         (rc = o.alloc((size_t)capacity * 16)) || (rc = oa.alloc((size_t)capacity * 4)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
     Counters hc{};
-    hc.n_kp = (int)n;
+    hc.n_kp[0] = (int)n;
     HIPCHK(hipMemcpy(cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice));
     BlurPlanes bp;
     for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
     hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, bp, W, H, octsize,
-                       par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), (int)n,
+                       par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
                        o.as<float4>(), oa.as<int>(), (int)capacity, (int)capacity);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
@@ -869,7 +868,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
     for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
     if (n > 0)
         hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(256), 0, 0, bp, W, H, octsize,
-                           (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, (int)n,
+                           (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
                            (int)n, r.as<KpRecord>());
     if ((rc = stage_end())) return rc;
     std::vector<KpRecord> h((size_t)n);

@@ -1,0 +1,99 @@
+"""GPU parity at the BASELINE.json sizes, plus the committed golden vectors replayed through the
+HIP path.  The oracle (OpenMP) finishes a 4096x4096 image in about a second on the GPU box's host
+cores, so full-size parity is checked directly, bit for bit, in addition to size-independent
+properties (determinism of the keypoint set, bounds, plan reuse, record/descriptor consistency)."""
+import os
+
+import numpy as np
+import pytest
+
+from util import (assert_same_keypoints, compare_keypoints_libm, multiscale_noise, rectangles, smooth_noise,
+                  sort_kp, sort_rows, white_noise)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name,maker,shape", [("white512", white_noise, (512, 512)), ("smooth512", smooth_noise, (512, 512)),
+                                              ("multi300x421", multiscale_noise, (300, 421)),
+                                              ("rect257x511", rectangles, (257, 511))])
+def test_golden_final_keypoints(siftlib, name, maker, shape):
+    """HIP output against vectors produced by the reference's own kernels (glibc math): x, y exact,
+    scale/angle within 2 ulp, descriptor bins within 1 LSB in <= 1 % of rows (measured: 0 bins)."""
+    import sift_pyocl_amd as sp
+    g = np.load(os.path.join(GOLD, "kp_%s.npz" % name))
+    img = maker(shape)
+    got = sp.SiftPlan(template=img).keypoints(img)
+    stats = compare_keypoints_libm(got, g["kp"], name)
+    assert stats["desc_bins_differing"] == 0
+
+
+def test_4096_white_noise_bit_exact(siftlib, oracle):
+    """BASELINE.json configs[1]: 4096x4096 fp32, 3 octaves x 3 scales -- and all 9 octaves."""
+    import sift_pyocl_amd as sp
+    img = white_noise((4096, 4096), seed=0)
+    plan3 = sp.SiftPlan(template=img, octave_max=3)
+    got3 = plan3.keypoints(img)
+    assert_same_keypoints(got3, oracle.keypoints(img, oracle.default_params(octave_max=3)), "4096 white, 3 octaves")
+    plan = sp.SiftPlan(template=img)
+    assert plan.octave_max == 9 and plan.kpsize == 4096 * 4096 // 10
+    got = plan.keypoints(img)
+    assert_same_keypoints(got, oracle.keypoints(img), "4096 white, all octaves")
+    assert 9000 < len(got) < 13000 and not plan.overflow
+    # properties: inside the image, positive scale, angles in [-pi, pi], set is reproducible
+    assert (got.x >= 0).all() and (got.x < 4096).all() and (got.y >= 0).all() and (got.y < 4096).all()
+    assert (got.scale > 1.0).all() and (np.abs(got.angle) <= np.float32(np.pi)).all()
+    assert_same_keypoints(got, plan.keypoints(img), "second call on the same plan")
+    sub = {r.tobytes() for r in got3}
+    assert sub.issubset({r.tobytes() for r in got}), "3-octave result must be a subset of the full one"
+
+
+def test_2048_keypoint_rich_bit_exact(siftlib, oracle):
+    import sift_pyocl_amd as sp
+    img = smooth_noise((2048, 2048), seed=3)
+    got = sp.SiftPlan(template=img).keypoints(img)
+    assert len(got) > 30000
+    assert_same_keypoints(got, oracle.keypoints(img), "2048 smoothed noise")
+
+
+def test_odd_sizes_and_borders(siftlib, oracle):
+    import sift_pyocl_amd as sp
+    for shape in [(1031, 1537), (2050, 1026), (1024, 4100)]:
+        img = smooth_noise(shape, seed=shape[0])
+        got = sp.SiftPlan(template=img).keypoints(img)
+        assert_same_keypoints(got, oracle.keypoints(img), str(shape))
+
+
+def test_capacity_overflow_is_reported(siftlib):
+    import sift_pyocl_amd as sp
+    img = smooth_noise((512, 512))
+    plan = sp.SiftPlan(template=img, PIX_PER_KP=1000)      # kpsize 262 << ~2400 keypoints
+    got = plan.keypoints(img)
+    assert plan.overflow and len(got) <= plan.kpsize
+
+
+def test_match_100k_properties(siftlib, oracle):
+    """BASELINE.json configs[4] shape (100k x 100k): too slow for the scalar oracle in full, so the oracle
+    checks a 2000-query slice and the rest is checked through properties."""
+    import sift_pyocl_amd as sp
+    from util import dtype_kp
+    n = 100000
+    rng = np.random.default_rng(1)
+    a = np.zeros(n, dtype_kp); a["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+    rng2 = np.random.default_rng(2)
+    b = np.zeros(n, dtype_kp)
+    perm = rng2.permutation(n)
+    half = n // 2
+    b["desc"][:half] = np.clip(a["desc"][perm[:half]].astype(np.int16) + rng2.integers(-8, 9, (half, 128)), 0, 255).astype(np.uint8)
+    b["desc"][half:] = rng2.integers(0, 256, (n - half, 128), dtype=np.uint8)
+    mp = sp.MatchPlan()
+    pairs = mp.match(a, b, raw_results=True)
+    assert len(pairs) == half                                   # every perturbed copy matches, random ones never do
+    inv = np.empty(n, np.int64); inv[perm[:half]] = np.arange(half)
+    assert (pairs[:, 1] == inv[pairs[:, 0]]).all()
+    assert len(np.unique(pairs[:, 0])) == half
+    sl = np.sort(rng.choice(n, 300, replace=False))
+    exp, total = oracle.match(a[sl], b)
+    got = pairs[np.isin(pairs[:, 0], sl)].copy()
+    got[:, 0] = np.searchsorted(sl, got[:, 0])
+    assert total == len(got) and np.array_equal(sort_rows(got), sort_rows(exp))

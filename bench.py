@@ -157,6 +157,15 @@ def main():
         mpix_total = world * K * size * size / 1e6
         value = mpix_total / elapsed
         blur_gbs = (8.0 * blur_px / 1e9) / (blur_ms / 1e3) if blur_ms > 0 else 0.0
+        # HBM traffic per blur launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE x2 + WRITE_SIZE, see tools/summarize_prof.py); null when absent or another config
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "blur_traffic.json")
+        if os.path.exists(tfile) and size == SIZE and n_oct == OCTAVES:
+            try:
+                traffic = round(json.load(open(tfile))["traffic_bytes_per_launch"], 1)
+            except Exception:
+                traffic = None
         kp_per_img = n_kp / max(K, 1)
         pipe_gbs = (bytes_alg(size, size, n_oct, kp_per_img) * K / 1e9) / (tot_ms / 1e3) if tot_ms > 0 else 0.0
         out = {
@@ -172,9 +181,9 @@ def main():
                                    % (size, size, n_oct),
                        "octaves": n_oct, "scales": 3, "keypoints_per_image": round(kp_per_img, 1),
                        "images_per_gpu_per_step": 1, "exchange": "rccl all_gather of keypoint records" if distributed else "none"},
-            "roofline": {"bound": "hbm", "kernel": "blur_hv_kernel<N,NORM> (all instances, %d launches/image)" % (blur_launches // max(K, 1)),
+            "roofline": {"bound": "hbm", "kernel": "blur_march_kernel<N,NORM> + blur_hv_kernel<N,NORM> (all instances, %d launches/image)" % (blur_launches // max(K, 1)),
                          "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(blur_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(blur_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_us": round(1e3 * blur_ms / max(blur_launches, 1), 2),
                          "alg_bytes_per_launch_avg": round(8.0 * blur_px / max(blur_launches, 1), 1)},
             "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Summarise a tools/collect_profiles.sh output directory: per-kernel calls / average duration from
+rocprofv3 --stats, and FETCH_SIZE / WRITE_SIZE per launch from the two PMC passes.
+
+HBM-traffic correction (MI355X_MICROARCH.md, section HBM): on gfx950 FETCH_SIZE reports half of the bytes
+of wide coalesced streaming reads; other access widths are uncalibrated, so this script calibrates on
+kernels of this very run whose byte counts are known: minmax_kernel (16-byte loads, reads exactly 4 B per
+pixel) and shrink_kernel / blur writes (4-byte or 8-byte stores of a known plane)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+
+
+def short(name):
+    name = name.replace("siftk::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
+stats = list(csv.DictReader(open(glob.glob(os.path.join(d, "kt", "*kernel_stats.csv"))[0])))
+print("== rocprofv3 --kernel-trace --stats (bench.py --steps 10 --warmup 2): per-kernel totals")
+print("%-46s %7s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+tot = sum(float(r["TotalDurationNs"]) for r in stats)
+fam = collections.defaultdict(lambda: [0, 0.0])
+for r in stats:
+    n = short(r["Name"])
+    print("%-46s %7s %12.1f %12.2f %7.2f" % (n[:46], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
+                                              100 * float(r["TotalDurationNs"]) / tot))
+    key = "blur (all instances)" if n.startswith("blur_") else n
+    fam[key][0] += int(r["Calls"]); fam[key][1] += float(r["TotalDurationNs"])
+print("\n== families")
+for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    print("%-46s calls %6d  total %10.1f us  avg %9.2f us  %5.1f %%" % (k, c, t / 1e3, t / c / 1e3, 100 * t / tot))
+
+
+def pmc(sub, counter):
+    f = glob.glob(os.path.join(d, sub, "*counter_collection.csv"))
+    if not f:
+        return {}
+    agg = collections.defaultdict(list)
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == counter:
+            per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Grid_Size"])] += float(r["Counter_Value"])
+    for (n, _, g), v in per.items():
+        agg[(n, g)].append(v)
+    return agg
+
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+print("\n== FETCH_SIZE / WRITE_SIZE per launch (KiB as reported, averaged over launches of the same grid)")
+print("%-40s %10s %6s %14s %14s" % ("kernel", "grid", "n", "FETCH_SIZE_KiB", "WRITE_SIZE_KiB"))
+keys = sorted(set(fetch) | set(write), key=lambda k: -sum(fetch.get(k, [0])))
+for k in keys[:40]:
+    fv = fetch.get(k, []); wv = write.get(k, [])
+    print("%-40s %10s %6d %14.0f %14.0f" % (k[0][:40], k[1], max(len(fv), len(wv)), sum(fv) / max(len(fv), 1), sum(wv) / max(len(wv), 1)))
+
+# ---- traffic of the dominant kernel family (blur), corrected: reads x2 (calibrated on minmax_kernel, whose
+# 16-byte loads read exactly 4 B/pixel and are reported at 1/2), writes x1 (blur / shrink stores are exact)
+import json
+cal = [v for (n, g), vs in fetch.items() if n == "minmax_kernel" for v in vs]
+nb = sum(len(v) for (n, g), v in fetch.items() if n.startswith("blur_"))
+fb = sum(sum(v) for (n, g), v in fetch.items() if n.startswith("blur_")) * 1024.0
+wb = sum(sum(v) for (n, g), v in write.items() if n.startswith("blur_")) * 1024.0
+nw = sum(len(v) for (n, g), v in write.items() if n.startswith("blur_"))
+if nb and nw:
+    out = {"kernel_family": "blur", "launches_fetch_pass": nb, "launches_write_pass": nw,
+           "fetch_size_bytes_per_launch_reported": fb / nb, "read_correction": 2.0,
+           "write_size_bytes_per_launch": wb / nw,
+           "traffic_bytes_per_launch": 2.0 * fb / nb + wb / nw,
+           "calibration": {"minmax_kernel_fetch_KiB_reported": sum(cal) / max(len(cal), 1), "expected_KiB": 65536},
+           "rocprof_avg_launch_us": fam["blur (all instances)"][1] / fam["blur (all instances)"][0] / 1e3}
+    print("\n== blur family traffic per launch (corrected):", json.dumps(out))
+    json.dump(out, open(os.path.join(d, "blur_traffic.json"), "w"), indent=1)

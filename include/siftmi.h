@@ -93,6 +93,10 @@ int siftmi_plan_profile(const siftmi_plan *plan, char *buf, int64_t buflen);
  * excluding host<->device copies; requires profile=1 at creation */
 int siftmi_plan_last_kernel_ms(const siftmi_plan *plan, float *total_ms, float *blur_ms, int32_t *blur_launches,
                                double *blur_pixels);
+/* the same restricted to the blur launches of one octave (octave < 0: all).  Octave-0 launches never run
+ * concurrently with another kernel of the plan, later octaves overlap the detection stream. */
+int siftmi_plan_blur_ms(const siftmi_plan *plan, int32_t octave, float *blur_ms, int32_t *blur_launches,
+                        double *blur_pixels);
 int siftmi_plan_destroy(siftmi_plan *plan);
 
 /* ---- MatchPlan -----------------------------------------------------------------------------

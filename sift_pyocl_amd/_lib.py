@@ -48,6 +48,8 @@ _SIGNATURES = {
     "siftmi_plan_profile": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "siftmi_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                              C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "siftmi_plan_blur_ms": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_double)]),
     "siftmi_plan_destroy": (C.c_int, [C.c_void_p]),
     "siftmi_match_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "siftmi_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,

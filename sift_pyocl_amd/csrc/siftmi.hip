@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <new>
 #include <string>
 #include <vector>
@@ -80,7 +81,7 @@ int kernel_size(double sigma) {   // utils.py:54-64 with odd=True, cutoff=4
 
 struct Taps { int n = 0; float t[64] = {0}; float *dev = nullptr; };
 
-struct Event { std::string label; hipEvent_t a = nullptr, b = nullptr; bool is_blur = false; double pixels = 0; };
+struct Event { std::string label; hipEvent_t a = nullptr, b = nullptr; bool is_blur = false; double pixels = 0; int octave = -1; };
 
 size_t dtype_size(int dt) {
     switch (dt) {
@@ -103,8 +104,13 @@ struct siftmi_plan {
     std::vector<int> ow, oh;
     int64_t kpsize = 0;
     int64_t bytes = 0;
-    float *blur[6] = {nullptr};
+    float *planes = nullptr;      // all octaves' blur planes: octave o, scale s at plane(o, s)
+    std::vector<size_t> oct_off;  // float offset of octave o's first plane
     float *tmp = nullptr;         // generic blur only
+    hipStream_t stream2 = nullptr;            // detection / description stream (overlaps the next octaves' pyramid)
+    std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
+    bool overlap = true;
+    float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
     void *raw = nullptr;          // host-input staging (any dtype)
     float *conv = nullptr;        // converted f32 input when dtype != f32
     uint32_t *mm = nullptr;
@@ -229,10 +235,11 @@ void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, cons
     if (!ok) launch_blur_generic(p->stream, in, out, p->tmp, W, H, t, p->mm, norm);
 }
 
-struct Scope {   // optional hipEvent bracket around one launch
-    siftmi_plan *p; size_t idx = (size_t)-1;
-    Scope(siftmi_plan *pl, const char *label, bool is_blur = false, double pixels = 0) : p(pl) {
-        if (!p->profile) return;
+struct Scope {   // optional hipEvent bracket around one launch (profile=1: blur launches only; 2: every stage)
+    siftmi_plan *p; size_t idx = (size_t)-1; hipStream_t st;
+    Scope(siftmi_plan *pl, const char *label, bool is_blur = false, double pixels = 0, hipStream_t s = nullptr, int octave = -1) : p(pl) {
+        st = s ? s : p->stream;
+        if (!p->profile || (p->profile == 1 && !is_blur)) return;
         if (p->n_events == p->events.size()) {
             Event e;
             hipEventCreate(&e.a); hipEventCreate(&e.b);
@@ -240,10 +247,10 @@ struct Scope {   // optional hipEvent bracket around one launch
         }
         idx = p->n_events++;
         Event &e = p->events[idx];
-        e.label = label; e.is_blur = is_blur; e.pixels = pixels;
-        hipEventRecord(e.a, p->stream);
+        e.label = label; e.is_blur = is_blur; e.pixels = pixels; e.octave = octave;
+        hipEventRecord(e.a, st);
     }
-    ~Scope() { if (idx != (size_t)-1) hipEventRecord(p->events[idx].b, p->stream); }
+    ~Scope() { if (idx != (size_t)-1) hipEventRecord(p->events[idx].b, st); }
 };
 
 int grid_for(int64_t n, int block, int max_blocks) {
@@ -258,9 +265,10 @@ double contrast_threshold(const siftmi_params &par) { return 0.8 * (double)par.p
 void launch_detect_octave(siftmi_plan *p, int oct) {
     const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
     const int octsize = 1 << oct;
+    hipStream_t st = p->overlap ? p->stream2 : p->stream;
     char lab[96];
     BlurPlanes bp;
-    for (int s = 0; s < 6; s++) bp.p[s] = p->blur[s];
+    for (int s = 0; s < 6; s++) bp.p[s] = p->plane(oct, s);
     const int border = p->par.border_dist;
     const int kcap = (int)p->kpsize;
     if (W > 2 * border && H > 2 * border) {
@@ -268,28 +276,30 @@ void launch_detect_octave(siftmi_plan *p, int oct) {
         const int blocks = (nx * ny + 3) / 4;
         const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
         snprintf(lab, sizeof lab, "local_maxmin %d", oct);
-        Scope sc(p, lab);
-        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, p->stream, bp, W, H, border,
+        Scope sc(p, lab, false, 0, st);
+        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border,
                            contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap);
     }
     {
         snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
-        Scope sc(p, lab);
-        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, p->stream, bp, W, H, (const float4 *)p->cand,
+        Scope sc(p, lab, false, 0, st);
+        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)p->cand,
                            (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
                            p->kp_scale, &p->cnt->n_kp[oct], kcap, (const int *)&p->cnt->n_out, &p->cnt->oct_start[oct],
                            &p->cnt->overflow);
     }
     {
         snprintf(lab, sizeof lab, "orientation_assignment %d", oct);
-        Scope sc(p, lab);
-        hipLaunchKernelGGL(orientation_kernel, dim3(1024), dim3(256), 0, p->stream, bp, W, H, octsize, p->par.ori_sigma,
+        Scope sc(p, lab, false, 0, st);
+        static const int ori_blocks = getenv("SIFTMI_ORI_BLOCKS") ? atoi(getenv("SIFTMI_ORI_BLOCKS")) : 1024;   // dev knob
+        hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), 0, st, bp, W, H, octsize, p->par.ori_sigma,
                            (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, oct, kcap, p->okp, p->oaux, kcap, kcap);
     }
     {
         snprintf(lab, sizeof lab, "descriptors %d", oct);
-        Scope sc(p, lab);
-        hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(256), 0, p->stream, bp, W, H, octsize,
+        Scope sc(p, lab, false, 0, st);
+        static const int desc_blocks = getenv("SIFTMI_DESC_BLOCKS") ? atoi(getenv("SIFTMI_DESC_BLOCKS")) : 2048;   // dev knob
+        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), 0, st, bp, W, H, octsize,
                            (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, oct, 0, 0, kcap, p->records);
     }
 }
@@ -356,7 +366,19 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     int rc = SIFTMI_OK;
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete p; return fail(SIFTMI_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    for (int s = 0; s < 6 && !rc; s++) rc = p->alloc(&p->blur[s], N * sizeof(float));
+    {
+        size_t off = 0;
+        for (int o = 0; o < p->n_oct; o++) { p->oct_off.push_back(off); off += 6 * (size_t)p->ow[(size_t)o] * p->oh[(size_t)o]; }
+        if (p->n_oct == 0) { p->oct_off.push_back(0); off = 6 * N; p->ow.assign(1, width); p->oh.assign(1, height); }
+        rc = p->alloc(&p->planes, off * sizeof(float));
+    }
+    if (!rc && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
+    p->overlap = getenv("SIFTMI_SINGLE_STREAM") == nullptr;
+    for (int o = 0; o < p->n_oct && !rc; o++) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
+        else p->ev_pyr.push_back(e);
+    }
     if (!rc) rc = p->alloc(&p->tmp, N * sizeof(float));
     if (!rc) rc = p->alloc(&p->raw, N * (dtype_size(in_dtype) > 4 ? dtype_size(in_dtype) : 4));
     if (!rc && in_dtype != SIFTMI_F32) rc = p->alloc(&p->conv, N * sizeof(float));
@@ -380,6 +402,8 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (!p) return SIFTMI_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
+    if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
+    for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
     for (Event &e : p->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (p->ev_first) hipEventDestroy(p->ev_first);
@@ -425,6 +449,9 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         HIPCHK(hipMemcpyAsync(p->raw, image, N * dtype_size(image_dtype), hipMemcpyHostToDevice, p->stream));
         src = p->raw;
     }
+    const bool htime = getenv("SIFTMI_HOST_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = tnow();
     p->n_events = 0;
 #ifdef SIFT_ABLATE
     apply_ablate();
@@ -454,38 +481,51 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, 2048)), dim3(256), 0, p->stream, f32src,
                            (int64_t)N, p->mm);
     }
+    float *base0 = p->plane(0, 0);
     if (p->have_init) {
-        Scope sc(p, "normalize + initial blur", true, (double)N);
-        launch_blur(p, f32src, p->blur[0], p->W, p->H, p->taps[5], true);
+        Scope sc(p, "normalize + initial blur", true, (double)N, nullptr, 0);
+        launch_blur(p, f32src, base0, p->W, p->H, p->taps[5], true);
     } else {
         Scope sc(p, "normalize");
         hipLaunchKernelGGL(normalize_kernel, dim3(grid_for((int64_t)N, 256, 4096)), dim3(256), 0, p->stream, f32src,
-                           p->blur[0], (int64_t)N, (const uint32_t *)p->mm);
+                           base0, (int64_t)N, (const uint32_t *)p->mm);
     }
     char lab[96];
+    // Stream `stream` builds the pyramid of every octave back to back; `stream2` runs detection /
+    // description of octave o as soon as its six planes exist, overlapping the (small, latency-bound)
+    // pyramids of the following octaves.  Octave planes are never rewritten, so the only ordering needed is
+    // one event per octave.
     for (int oct = 0; oct < p->n_oct; oct++) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
         for (int s = 0; s < 5; s++) {
             snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
-            Scope sc(p, lab, true, (double)W * H);
-            launch_blur(p, p->blur[s], p->blur[s + 1], W, H, p->taps[s], false);
+            Scope sc(p, lab, true, (double)W * H, nullptr, oct);
+            launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
         }
-        launch_detect_octave(p, oct);
         if (oct < p->n_oct - 1) {
             const int SW = p->ow[(size_t)oct + 1], SH = p->oh[(size_t)oct + 1];
             snprintf(lab, sizeof lab, "shrink %d", oct);
             Scope sc(p, lab);
             hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, p->stream,
-                               (const float *)p->blur[3], p->blur[0], W, SW, SH);
+                               (const float *)p->plane(oct, 3), p->plane(oct + 1, 0), W, SW, SH);
         }
+        if (p->overlap) {
+            HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], p->stream));
+            HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_pyr[(size_t)oct], 0));
+        }
+        launch_detect_octave(p, oct);
     }
-    if (p->profile) hipEventRecord(p->ev_last, p->stream);
+    hipStream_t fin = (p->overlap && p->n_oct > 0) ? p->stream2 : p->stream;
+    if (p->profile) hipEventRecord(p->ev_last, fin);
     Counters hc;
-    HIPCHK(hipMemcpyAsync(&hc, p->cnt, sizeof hc, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipMemcpyAsync(&hc, p->cnt, sizeof hc, hipMemcpyDeviceToHost, fin));
     uint32_t hmm[2];
-    HIPCHK(hipMemcpyAsync(hmm, p->mm, sizeof hmm, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipMemcpyAsync(hmm, p->mm, sizeof hmm, hipMemcpyDeviceToHost, fin));
+    const double t_enq = tnow();
+    HIPCHK(hipStreamSynchronize(fin));
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipGetLastError());
+    const double t_sync = tnow();
     {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
         p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
@@ -497,11 +537,12 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "output capacity too small; result truncated"; }
     if (n > 0) {
         HIPCHK(hipMemcpyAsync(out, p->records, (size_t)n * sizeof(KpRecord),
-                              out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, p->stream));
-        HIPCHK(hipStreamSynchronize(p->stream));
+                              out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, fin));
+        HIPCHK(hipStreamSynchronize(fin));
     }
     *n_out = n;
     if (overflow) *overflow = ovf;
+    if (htime) fprintf(stderr, "[siftmi] enqueue %.0f us, wait %.0f us, records copy %.0f us\n", t_enq - t_enter, t_sync - t_enq, tnow() - t_sync);
     return rc;
 }
 
@@ -532,14 +573,20 @@ int siftmi_plan_last_kernel_ms(const siftmi_plan *p, float *total_ms, float *blu
     if (!p->profile) return fail(SIFTMI_EINVAL, "plan was created with profile=0");
     float tot = 0;
     HIPCHK(hipEventElapsedTime(&tot, p->ev_first, p->ev_last));
+    if (total_ms) *total_ms = tot;
+    return siftmi_plan_blur_ms(p, -1, blur_ms, blur_launches, blur_pixels);
+}
+
+int siftmi_plan_blur_ms(const siftmi_plan *p, int32_t octave, float *blur_ms, int32_t *blur_launches, double *blur_pixels) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (!p->profile) return fail(SIFTMI_EINVAL, "plan was created with profile=0");
     float bms = 0; int bl = 0; double px = 0;
     for (size_t i = 0; i < p->n_events; i++)
-        if (p->events[i].is_blur) {
+        if (p->events[i].is_blur && (octave < 0 || p->events[i].octave == octave)) {
             float ms = 0;
             hipEventElapsedTime(&ms, p->events[i].a, p->events[i].b);
             bms += ms; bl++; px += p->events[i].pixels;
         }
-    if (total_ms) *total_ms = tot;
     if (blur_ms) *blur_ms = bms;
     if (blur_launches) *blur_launches = bl;
     if (blur_pixels) *blur_pixels = px;

@@ -104,6 +104,9 @@ class SiftPlan(object):
         if par.Scales != 3:
             raise RuntimeError("par.Scales is hard-wired to 3 in the kernels (as in image.cl:355)")
         self.profile = bool(profile)
+        # profile=True: hipEvent bracket around every stage (log_profile(), as the reference);
+        # profile="light": only the blur launches and the first/last kernel (what bench.py needs)
+        self._profile_level = 0 if not profile else (1 if profile == "light" else 2)
         self.events = []
         self._sem = threading.Semaphore()
         self.scales = []     # octave sizes in XY order, as the reference
@@ -140,7 +143,7 @@ class SiftPlan(object):
             raise RuntimeError("sift_pyocl_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
         self._params = self._current_params()
         _lib.check(L.siftmi_plan_create(self.shape[0], self.shape[1], self._code, self.device,
-                                        C.byref(self._params), int(self.profile), C.byref(self._handle)))
+                                        C.byref(self._params), self._profile_level, C.byref(self._handle)))
         nbytes = C.c_int64()
         _lib.check(L.siftmi_plan_info(self._handle, None, None, C.byref(nbytes)))
         self.memory = int(nbytes.value)
@@ -272,7 +275,10 @@ class SiftPlan(object):
         tot, blur = C.c_float(), C.c_float()
         nl, px = C.c_int32(), C.c_double()
         _lib.check(_lib.lib().siftmi_plan_last_kernel_ms(self._handle, C.byref(tot), C.byref(blur), C.byref(nl), C.byref(px)))
-        return dict(total_ms=tot.value, blur_ms=blur.value, blur_launches=nl.value, blur_pixels=px.value)
+        out = dict(total_ms=tot.value, blur_ms=blur.value, blur_launches=nl.value, blur_pixels=px.value)
+        _lib.check(_lib.lib().siftmi_plan_blur_ms(self._handle, 0, C.byref(blur), C.byref(nl), C.byref(px)))
+        out.update(blur0_ms=blur.value, blur0_launches=nl.value, blur0_pixels=px.value)
+        return out
 
     def log_profile(self):
         """If profiling is on, print the device time of every stage of the last call."""

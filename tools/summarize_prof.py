@@ -36,6 +36,26 @@ for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print("%-46s calls %6d  total %10.1f us  avg %9.2f us  %5.1f %%" % (k, c, t / 1e3, t / c / 1e3, 100 * t / tot))
 
 
+# per (kernel, grid) durations from the kernel trace: the octave-0 (largest grid) rows of the blur instances are
+# what bench.py's roofline object is computed from (hipEvent) -- compare avg_us here with its avg_launch_us
+trace = list(csv.DictReader(open(glob.glob(os.path.join(d, "kt", "*kernel_trace.csv"))[0])))
+per = collections.defaultdict(list)
+for r in trace:
+    per[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("\n== kernel trace by (kernel, grid threads): calls, avg_us, min_us")
+b0_t = b0_n = 0
+bigg = {}
+for (n, g) in per:
+    if n.startswith("blur_"):
+        bigg[n] = max(bigg.get(n, 0), g)
+for (n, g), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+    print("%-40s %10d %6d %10.2f %10.2f" % (n[:40], g, len(v), sum(v) / len(v), min(v)))
+    if n.startswith("blur_") and g == bigg[n]:
+        b0_t += sum(v); b0_n += len(v)
+if b0_n:
+    print("full-resolution blur launches: %d calls, avg %.2f us" % (b0_n, b0_t / b0_n))
+
+
 def pmc(sub, counter):
     f = glob.glob(os.path.join(d, sub, "*counter_collection.csv"))
     if not f:
@@ -62,16 +82,22 @@ for k in keys[:40]:
 # 16-byte loads read exactly 4 B/pixel and are reported at 1/2), writes x1 (blur / shrink stores are exact)
 import json
 cal = [v for (n, g), vs in fetch.items() if n == "minmax_kernel" for v in vs]
-nb = sum(len(v) for (n, g), v in fetch.items() if n.startswith("blur_"))
-fb = sum(sum(v) for (n, g), v in fetch.items() if n.startswith("blur_")) * 1024.0
-wb = sum(sum(v) for (n, g), v in write.items() if n.startswith("blur_")) * 1024.0
-nw = sum(len(v) for (n, g), v in write.items() if n.startswith("blur_"))
+# full-resolution launches only (the largest grid of each blur instance), as bench.py's roofline object
+big = {}
+for (n, g) in list(fetch) + list(write):
+    if n.startswith("blur_"):
+        big[n] = max(big.get(n, 0), int(g))
+sel = lambda n, g: n.startswith("blur_") and int(g) == big[n]
+nb = sum(len(v) for (n, g), v in fetch.items() if sel(n, g))
+fb = sum(sum(v) for (n, g), v in fetch.items() if sel(n, g)) * 1024.0
+wb = sum(sum(v) for (n, g), v in write.items() if sel(n, g)) * 1024.0
+nw = sum(len(v) for (n, g), v in write.items() if sel(n, g))
 if nb and nw:
-    out = {"kernel_family": "blur", "launches_fetch_pass": nb, "launches_write_pass": nw,
+    out = {"kernel_family": "blur, full-resolution (octave 0) launches", "launches_fetch_pass": nb, "launches_write_pass": nw,
            "fetch_size_bytes_per_launch_reported": fb / nb, "read_correction": 2.0,
            "write_size_bytes_per_launch": wb / nw,
            "traffic_bytes_per_launch": 2.0 * fb / nb + wb / nw,
            "calibration": {"minmax_kernel_fetch_KiB_reported": sum(cal) / max(len(cal), 1), "expected_KiB": 65536},
-           "rocprof_avg_launch_us": fam["blur (all instances)"][1] / fam["blur (all instances)"][0] / 1e3}
+           "rocprof_avg_launch_us_all_blur_launches": fam["blur (all instances)"][1] / fam["blur (all instances)"][0] / 1e3}
     print("\n== blur family traffic per launch (corrected):", json.dumps(out))
     json.dump(out, open(os.path.join(d, "blur_traffic.json"), "w"), indent=1)

@@ -64,6 +64,13 @@ __global__ void begin_image_kernel(Counters *c) {
     if (t < SIFT_MAX_OCTAVES) { c->n_cand[t] = 0; c->n_kp[t] = 0; c->oct_start[t] = 0; }
 }
 
+#ifdef SIFT_ABLATE
+__device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/exp, 3 refill only
+#define ABL(x) (g_ablate == (x))
+#else
+#define ABL(x) false
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Orientation assignment: one wave per refined keypoint (orientation_cpu.cl:41-174).
 // Output goes straight to the image-wide oriented list (x, y, sigma*oct, angle) + detection scale.
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, i
         const int nmain = (sum4 == sum4) ? 1 : 0;     // host NaN sieve of plan.py:545-550, done here
         const int nextra = __popcll((unsigned long long)emask);
         int slot0 = 0;
-        if (lane == 0 && nmain + nextra > 0) slot0 = atomicAdd(&cnt->n_out, nmain + nextra);
+        if (lane == 0 && nmain + nextra > 0) slot0 = ABL(4) ? (oct_start + i * 4) : atomicAdd(&cnt->n_out, nmain + nextra);
         slot0 = __shfl(slot0, 0);
         if (lane == 0 && nmain) {
             if (slot0 < out_capacity && slot0 - oct_start < per_octave_capacity) {
@@ -196,13 +203,6 @@ __global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, i
 //     the reference's sequence of float additions.
 // Waves of a block are independent (4 keypoints per 256-thread block); latency is hidden by
 // occupancy instead of by barriers.
-#ifdef SIFT_ABLATE
-__device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/exp, 3 refill only
-#define ABL(x) (g_ablate == (x))
-#else
-#define ABL(x) false
-#endif
-
 struct DescWaveLds {
     uint4 binfo[128];             // per bin: {mask lo, mask hi, pool base, -} : 64-bit mask of contributing lanes
     float pool[8 * 64];           // contribution values, grouped by bin, in lane (= raster) order inside a bin

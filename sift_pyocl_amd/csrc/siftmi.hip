@@ -478,7 +478,9 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     {
         Scope sc(p, "max_min");
         hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, p->stream, p->mm);
-        hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, 2048)), dim3(256), 0, p->stream, f32src,
+        // few, fat workgroups: every block ends with two atomics on the same cache line
+        static const int mm_blocks = getenv("SIFTMI_MM_BLOCKS") ? atoi(getenv("SIFTMI_MM_BLOCKS")) : 256;
+        hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, mm_blocks)), dim3(256), 0, p->stream, f32src,
                            (int64_t)N, p->mm);
     }
     float *base0 = p->plane(0, 0);
@@ -606,6 +608,8 @@ struct siftmi_matcher {
     int64_t cap1 = 0, cap2 = 0;
     int2 *pairs = nullptr;
     int64_t cap_pairs = 0;
+    MatchPartial *partial = nullptr;
+    int64_t cap_partial = 0;
     int *counter = nullptr;
     hipEvent_t ea = nullptr, eb = nullptr;
     float last_ms = 0;
@@ -655,6 +659,7 @@ int siftmi_match_destroy(siftmi_matcher *m) {
     if (m->kp1) hipFree(m->kp1);
     if (m->kp2) hipFree(m->kp2);
     if (m->pairs) hipFree(m->pairs);
+    if (m->partial) hipFree(m->partial);
     if (m->counter) hipFree(m->counter);
     if (m->ea) hipEventDestroy(m->ea);
     if (m->eb) hipEventDestroy(m->eb);
@@ -691,10 +696,21 @@ int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int3
     if ((n1 < n2 ? n1 : n2) > cap) cap = (n1 < n2 ? n1 : n2);
     if ((rc = ensure((void **)&m->pairs, &m->cap_pairs, cap, sizeof(int2)))) return rc;
     HIPCHK(hipMemsetAsync(m->counter, 0, 4, m->stream));
-    const int blocks = (int)((n1 + 256 * SIFT_MATCH_QPT - 1) / (256 * SIFT_MATCH_QPT));
+    // 2-D decomposition: query blocks x partitions of the second list, enough workgroups to fill 256 CUs
+    const int qblocks = (int)((n1 + 256 * SIFT_MATCH_QPT - 1) / (256 * SIFT_MATCH_QPT));
+    int nparts = (2048 + qblocks - 1) / qblocks;
+    const int max_parts = (int)((n2 + 4 * SIFT_MATCH_TILE - 1) / (4 * SIFT_MATCH_TILE));
+    if (nparts > max_parts) nparts = max_parts;
+    if (nparts < 1) nparts = 1;
+    int part_len = (int)((n2 + nparts - 1) / nparts);
+    part_len = (part_len + SIFT_MATCH_TILE - 1) / SIFT_MATCH_TILE * SIFT_MATCH_TILE;
+    nparts = (int)((n2 + part_len - 1) / part_len);
+    if ((rc = ensure((void **)&m->partial, &m->cap_partial, (int64_t)nparts * n1, sizeof(MatchPartial)))) return rc;
     hipEventRecord(m->ea, m->stream);
-    hipLaunchKernelGGL(match_kernel, dim3((unsigned)blocks), dim3(256), 0, m->stream, d1, (int)n1, d2, (int)n2, ratio_th,
-                       m->pairs, m->counter, (int)cap);
+    hipLaunchKernelGGL(match_partial_kernel, dim3((unsigned)qblocks, (unsigned)nparts), dim3(256), 0, m->stream, d1, (int)n1,
+                       d2, (int)n2, part_len, m->partial);
+    hipLaunchKernelGGL(match_merge_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, m->stream,
+                       (const MatchPartial *)m->partial, (int)n1, nparts, ratio_th, m->pairs, m->counter, (int)cap);
     hipEventRecord(m->eb, m->stream);
     int count = 0;
     HIPCHK(hipMemcpyAsync(&count, m->counter, 4, hipMemcpyDeviceToHost, m->stream));

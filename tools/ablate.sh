@@ -1,6 +1,7 @@
 #!/bin/bash
-# dev helper: run the stage profiler against the ablation build (libsiftmi_ablate.so)
+# dev helper: run the stage profiler against the ablation build (libsiftmi_ablate.so); args: image kind, ablate codes...
 cp sift_pyocl_amd/libsiftmi.so /tmp/libsiftmi_keep.so
 cp sift_pyocl_amd/libsiftmi_ablate.so sift_pyocl_amd/libsiftmi.so
-for a in 0 1 2 3; do echo "== ablate $a"; SIFTMI_ABLATE=$a python tools/stage_profile.py 4096 ${1:-white} 3 2>&1 | grep -E "descriptors  |TOTAL"; done
+kind=${1:-white}; shift
+for a in "$@"; do echo "== ablate $a"; SIFTMI_SINGLE_STREAM=1 SIFTMI_ABLATE=$a python tools/stage_profile.py 4096 $kind 3 2>&1 | grep -E "descriptors  |orientation_assignment  |TOTAL"; done
 cp /tmp/libsiftmi_keep.so sift_pyocl_amd/libsiftmi.so

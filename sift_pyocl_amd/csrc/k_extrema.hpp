@@ -118,15 +118,11 @@ __global__ __launch_bounds__(256) void extrema_kernel(BlurPlanes b, int W, int H
 __global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H, const float4 *__restrict__ cand,
                                                      const int *__restrict__ n_cand, int cand_capacity,
                                                      float peak_thresh, float init_sigma,
-                                                     float4 *__restrict__ kp, int *__restrict__ kp_scale,
-                                                     int *__restrict__ n_kp, int kp_capacity,
-                                                     const int *__restrict__ n_out, int *__restrict__ oct_start,
+                                                     float4 *__restrict__ kp, int *__restrict__ kp_aux,
+                                                     int *__restrict__ n_kp, int kp_capacity, int oct,
                                                      int *__restrict__ overflow) {
     const int n = min(*n_cand, cand_capacity);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (oct_start) *oct_start = *n_out;          // first record index of this octave
-        if (*n_cand > cand_capacity && overflow) *overflow = 1;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > cand_capacity && overflow) *overflow = 1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 k = cand[i];
         int r = (int)k.y, c = (int)k.z;
@@ -188,7 +184,7 @@ __global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H,
             const int slot = atomicAdd(n_kp, 1);
             if (slot < kp_capacity) {
                 kp[slot] = make_float4(peak, (float)r + s1, (float)c + s2, sig);
-                kp_scale[slot] = scale;
+                kp_aux[slot] = scale | (oct << 8);
             }
         }
     }

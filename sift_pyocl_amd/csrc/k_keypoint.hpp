@@ -45,23 +45,44 @@ __device__ __forceinline__ int div_exact(int idx, int d, float inv, int &rem) {
     return q;
 }
 
-// device counters.  Per-octave slots are zeroed once per image, so no kernel has to reset anything
-// between octaves; oct_start[o] is recorded by the refine kernel of octave o (stream order puts it
-// after the descriptor kernel of octave o-1 and before the orientation kernel of octave o).
+// Device-side bookkeeping.  Refined keypoints of every octave are appended to ONE list (tagged with their
+// octave), so the per-keypoint kernels can be launched once per GROUP of octaves instead of once per
+// octave: group 0 = octave 0 (starts as soon as its pyramid exists), group 1 = all later octaves
+// (whose few keypoints would otherwise pay one latency-bound launch chain per octave).
 #define SIFT_MAX_OCTAVES 24
+#define SIFT_GROUPS 2
 struct Counters {
-    int n_out;                          // oriented keypoints, all octaves so far (index into the record list)
+    int n_out;                          // oriented keypoints so far (index into the record list)
     int overflow;                       // set when a list hit its capacity
-    int pad[2];
+    int n_kp;                           // refined keypoints so far, all octaves
+    int pad;
+    int grp_kp_start[SIFT_GROUPS + 1];  // refined-list start of each group
+    int grp_out_start[SIFT_GROUPS + 1]; // record-list range of each group, closed by mark_group_kernel
+    int grp_out_end[SIFT_GROUPS + 1];
     int n_cand[SIFT_MAX_OCTAVES];       // candidates per octave
-    int n_kp[SIFT_MAX_OCTAVES];         // refined keypoints per octave
-    int oct_start[SIFT_MAX_OCTAVES];    // n_out at the start of each octave
 };
+
+// where the six planes of every octave live: plane(o, s) = base + off[o] + s * W[o] * H[o]
+struct OctaveTable {
+    const float *base;
+    long long off[SIFT_MAX_OCTAVES];
+    int W[SIFT_MAX_OCTAVES], H[SIFT_MAX_OCTAVES];
+};
+
+// Runs after the orientation kernel of group g: freezes the group's record range (the descriptor kernel of g
+// may then run while the next group appends) and opens the next group's ranges.
+__global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_capacity) {
+    const int kp_end = min(c->n_kp, kp_capacity), out_end = min(c->n_out, out_capacity);
+    c->grp_out_end[g] = out_end;
+    c->grp_kp_start[g + 1] = kp_end;
+    c->grp_out_start[g + 1] = out_end;
+}
 
 __global__ void begin_image_kernel(Counters *c) {
     const int t = threadIdx.x;
-    if (t == 0) { c->n_out = 0; c->overflow = 0; }
-    if (t < SIFT_MAX_OCTAVES) { c->n_cand[t] = 0; c->n_kp[t] = 0; c->oct_start[t] = 0; }
+    if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; }
+    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; }
+    if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
 }
 
 #ifdef SIFT_ABLATE
@@ -74,23 +95,24 @@ __device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/
 // ------------------------------------------------------------------------------------------
 // Orientation assignment: one wave per refined keypoint (orientation_cpu.cl:41-174).
 // Output goes straight to the image-wide oriented list (x, y, sigma*oct, angle) + detection scale.
-__global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, int H, int octsize, float ori_sigma,
+__global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float ori_sigma,
                                                           const float4 *__restrict__ kp,
-                                                          const int *__restrict__ kp_scale, Counters *cnt, int oct,
+                                                          const int *__restrict__ kp_aux, Counters *cnt, int group,
                                                           int kp_capacity, float4 *__restrict__ okp,
-                                                          int *__restrict__ oaux, int out_capacity,
-                                                          int per_octave_capacity) {
+                                                          int *__restrict__ oaux, int out_capacity) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int n = min(cnt->n_kp[oct], kp_capacity);
-    if (cnt->n_kp[oct] > kp_capacity && threadIdx.x == 0 && blockIdx.x == 0) cnt->overflow = 1;
-    const int oct_start = cnt->oct_start[oct];
-    for (int i = wave; i < n; i += nwaves) {
+    const int n = min(cnt->n_kp, kp_capacity);
+    const int first = cnt->grp_kp_start[group];
+    if (threadIdx.x == 0 && blockIdx.x == 0 && cnt->n_kp > kp_capacity) cnt->overflow = 1;
+    for (int i = first + wave; i < n; i += nwaves) {
         const float4 k = kp[i];          // (peak, row, col, sigma)
-        const int scale = kp_scale[i];
+        const int aux = kp_aux[i];       // detection scale | octave << 8
+        const int scale = aux & 0xff, oct = aux >> 8;
+        const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
         if (!(k.y >= 0.0f)) continue;
-        const float *I = b.p[scale];
+        const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
         const int row = (int)((double)k.y + 0.5), col = (int)((double)k.z + 0.5);
         const float sigma = ori_sigma * k.w;
         const int radius = (int)((double)sigma * 3.0);
@@ -170,19 +192,19 @@ __global__ __launch_bounds__(256) void orientation_kernel(BlurPlanes b, int W, i
         const int nmain = (sum4 == sum4) ? 1 : 0;     // host NaN sieve of plan.py:545-550, done here
         const int nextra = __popcll((unsigned long long)emask);
         int slot0 = 0;
-        if (lane == 0 && nmain + nextra > 0) slot0 = ABL(4) ? (oct_start + i * 4) : atomicAdd(&cnt->n_out, nmain + nextra);
+        if (lane == 0 && nmain + nextra > 0) slot0 = ABL(4) ? (i * 4) : atomicAdd(&cnt->n_out, nmain + nextra);
         slot0 = __shfl(slot0, 0);
         if (lane == 0 && nmain) {
-            if (slot0 < out_capacity && slot0 - oct_start < per_octave_capacity) {
+            if (slot0 < out_capacity) {
                 okp[slot0] = make_float4(ox, oy, os, angle);
-                oaux[slot0] = scale;
+                oaux[slot0] = aux;
             } else cnt->overflow = 1;
         }
         if (extra) {
             const int slot = slot0 + nmain + __popcll((unsigned long long)(emask & ((1ull << lane) - 1ull)));
-            if (slot < out_capacity && slot - oct_start < per_octave_capacity) {
+            if (slot < out_capacity) {
                 okp[slot] = make_float4(ox, oy, os, a2);
-                oaux[slot] = scale;
+                oaux[slot] = aux;
             } else cnt->overflow = 1;
         }
     }
@@ -212,30 +234,33 @@ struct DescWaveLds {
     float V[128];
 };
 
-__global__ __launch_bounds__(256) void descriptor_kernel(BlurPlanes b, int W, int H, int octsize,
-                                                         const float4 *__restrict__ okp,
-                                                         const int *__restrict__ oaux, const Counters *cnt, int oct,
+__global__ __launch_bounds__(256) void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp,
+                                                         const int *__restrict__ oaux, const Counters *cnt, int group,
                                                          int range_start, int range_end,  // used when cnt == nullptr
                                                          int out_capacity, KpRecord *__restrict__ records) {
     __shared__ DescWaveLds lds_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescWaveLds &L = lds_all[wave];
     int start = range_start, end = range_end;
-    if (cnt) { start = cnt->oct_start[oct]; end = min(cnt->n_out, out_capacity); }
+    if (cnt) {
+        start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity);
+    }
     L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u); L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
     if (lane == 0) L.pool_cnt = 0;
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int i = start + gwave; i < end; i += nwaves) {
         const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
-        const int scale = oaux[i];
+        const int aux = oaux[i];         // detection scale | octave << 8
+        const int scale = aux & 0xff, oct = aux >> 8;
+        const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
         KpRecord *rec = records + i;
         if (!(kq.y >= 0.0f)) {
             if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
             reinterpret_cast<uint16_t *>(rec->desc)[lane] = 0;
             continue;
         }
-        const float *I = b.p[scale];
+        const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
         const float foct = (float)octsize;
         const float row = kq.y / foct, col = kq.x / foct, angle = kq.w;
         const int irow = (int)(row + 0.5f), icol = (int)(col + 0.5f);

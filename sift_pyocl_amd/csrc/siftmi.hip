@@ -107,7 +107,9 @@ struct siftmi_plan {
     float *planes = nullptr;      // all octaves' blur planes: octave o, scale s at plane(o, s)
     std::vector<size_t> oct_off;  // float offset of octave o's first plane
     float *tmp = nullptr;         // generic blur only
-    hipStream_t stream2 = nullptr;            // detection / description stream (overlaps the next octaves' pyramid)
+    hipStream_t stream2 = nullptr;            // detection / description of octave 0 (overlaps the next octaves' pyramid)
+    hipStream_t stream3 = nullptr;            // detection / description of the later octaves (overlaps group 0's descriptors)
+    hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr;
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
@@ -262,10 +264,23 @@ int grid_for(int64_t n, int block, int max_blocks) {
 
 double contrast_threshold(const siftmi_params &par) { return 0.8 * (double)par.peak_thresh; }   // image.cl:152
 
-void launch_detect_octave(siftmi_plan *p, int oct) {
+OctaveTable octave_table(const siftmi_plan *p) {
+    OctaveTable tab;
+    memset(&tab, 0, sizeof tab);
+    tab.base = p->planes;
+    for (int o = 0; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) {
+        tab.off[o] = (long long)p->oct_off[(size_t)o];
+        tab.W[o] = p->ow[(size_t)o];
+        tab.H[o] = p->oh[(size_t)o];
+    }
+    return tab;
+}
+
+// extrema of the three detection scales + sub-pixel refinement of one octave; survivors are appended to the
+// image-wide refined list (tagged with the octave)
+void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
     const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
     const int octsize = 1 << oct;
-    hipStream_t st = p->overlap ? p->stream2 : p->stream;
     char lab[96];
     BlurPlanes bp;
     for (int s = 0; s < 6; s++) bp.p[s] = p->plane(oct, s);
@@ -285,22 +300,30 @@ void launch_detect_octave(siftmi_plan *p, int oct) {
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)p->cand,
                            (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
-                           p->kp_scale, &p->cnt->n_kp[oct], kcap, (const int *)&p->cnt->n_out, &p->cnt->oct_start[oct],
-                           &p->cnt->overflow);
+                           p->kp_scale, &p->cnt->n_kp, kcap, oct, &p->cnt->overflow);
     }
+}
+
+// orientation + descriptor for every refined keypoint of one group of octaves
+void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
+    const int kcap = (int)p->kpsize;
+    const OctaveTable tab = octave_table(p);
+    char lab[96];
     {
-        snprintf(lab, sizeof lab, "orientation_assignment %d", oct);
+        snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
         Scope sc(p, lab, false, 0, st);
         static const int ori_blocks = getenv("SIFTMI_ORI_BLOCKS") ? atoi(getenv("SIFTMI_ORI_BLOCKS")) : 1024;   // dev knob
-        hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), 0, st, bp, W, H, octsize, p->par.ori_sigma,
-                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, oct, kcap, p->okp, p->oaux, kcap, kcap);
+        hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), 0, st, tab, p->par.ori_sigma,
+                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap);
     }
+    hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap);
+    if (group == 0 && p->overlap) hipEventRecord(p->ev_mark0, st);   // later octaves may start appending now
     {
-        snprintf(lab, sizeof lab, "descriptors %d", oct);
+        snprintf(lab, sizeof lab, "descriptors group %d", group);
         Scope sc(p, lab, false, 0, st);
         static const int desc_blocks = getenv("SIFTMI_DESC_BLOCKS") ? atoi(getenv("SIFTMI_DESC_BLOCKS")) : 2048;   // dev knob
-        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), 0, st, bp, W, H, octsize,
-                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, oct, 0, 0, kcap, p->records);
+        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), 0, st, tab,
+                           (const float4 *)p->okp, (const int *)p->oaux, p->cnt, group, 0, 0, kcap, p->records);
     }
 }
 
@@ -373,6 +396,9 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
         rc = p->alloc(&p->planes, off * sizeof(float));
     }
     if (!rc && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
+    if (!rc && hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
+    if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_grp1, hipEventDisableTiming) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
     p->overlap = getenv("SIFTMI_SINGLE_STREAM") == nullptr;
     for (int o = 0; o < p->n_oct && !rc; o++) {
         hipEvent_t e;
@@ -403,6 +429,9 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
     if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
+    if (p->stream3) { hipStreamSynchronize(p->stream3); hipStreamDestroy(p->stream3); }
+    if (p->ev_mark0) hipEventDestroy(p->ev_mark0);
+    if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
     for (Event &e : p->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -511,11 +540,23 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
             hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, p->stream,
                                (const float *)p->plane(oct, 3), p->plane(oct + 1, 0), W, SW, SH);
         }
+        // group 0 = octave 0 on stream2, described right away; group 1 = every later octave on stream3: it
+        // starts once group 0's orientation pass has frozen its ranges and overlaps group 0's descriptors
+        hipStream_t dst = !p->overlap ? p->stream : (oct == 0 ? p->stream2 : p->stream3);
         if (p->overlap) {
             HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], p->stream));
-            HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_pyr[(size_t)oct], 0));
+            if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
+            HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
         }
-        launch_detect_octave(p, oct);
+        launch_detect_octave(p, oct, dst);
+        if (oct == 0) launch_describe_group(p, 0, dst);
+        else if (oct == p->n_oct - 1) {
+            launch_describe_group(p, 1, dst);
+            if (p->overlap) {
+                HIPCHK(hipEventRecord(p->ev_grp1, dst));
+                HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_grp1, 0));   // stream2 ends last
+            }
+        }
     }
     hipStream_t fin = (p->overlap && p->n_oct > 0) ? p->stream2 : p->stream;
     if (p->profile) hipEventRecord(p->ev_last, fin);
@@ -867,10 +908,10 @@ int siftmi_stage_interp(int32_t dev, const float *blurs, int32_t W, int32_t H, c
     Counters *dc = cnt.as<Counters>();
     hipLaunchKernelGGL(refine_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, 0, bp, W, H, (const float4 *)c.as<float4>(),
                        (const int *)&dc->n_cand[0], (int)n, par->peak_thresh, (float)par->init_sigma, k.as<float4>(),
-                       ks.as<int>(), &dc->n_kp[0], (int)n, (const int *)nullptr, (int *)nullptr, (int *)nullptr);
+                       ks.as<int>(), &dc->n_kp, (int)n, 0, (int *)nullptr);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
-    const int64_t m = hc.n_kp[0];
+    const int64_t m = hc.n_kp;
     if (m > 0) {
         HIPCHK(hipMemcpy(out, k.p, (size_t)m * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out_scale, ks.p, (size_t)m * 4, hipMemcpyDeviceToHost));
@@ -902,19 +943,27 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = k.upload(kps, (size_t)n * 16)) || (rc = ks.upload(kp_scale, (size_t)n * 4)) ||
         (rc = o.alloc((size_t)capacity * 16)) || (rc = oa.alloc((size_t)capacity * 4)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
     Counters hc{};
-    hc.n_kp[0] = (int)n;
+    hc.n_kp = (int)n;
     HIPCHK(hipMemcpy(cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice));
-    BlurPlanes bp;
-    for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
-    hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, bp, W, H, octsize,
+    int oct = 0;
+    while ((1 << oct) < octsize && oct < SIFT_MAX_OCTAVES - 1) oct++;
+    if ((1 << oct) != octsize) return fail(SIFTMI_EINVAL, "octsize must be a power of two");
+    OctaveTable tab;
+    memset(&tab, 0, sizeof tab);
+    tab.base = b.as<float>(); tab.off[oct] = 0; tab.W[oct] = W; tab.H[oct] = H;
+    std::vector<int32_t> aux((size_t)n);
+    for (int64_t i = 0; i < n; i++) aux[(size_t)i] = kp_scale[i] | (oct << 8);
+    HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
                        par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
-                       o.as<float4>(), oa.as<int>(), (int)capacity, (int)capacity);
+                       o.as<float4>(), oa.as<int>(), (int)capacity);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
     int64_t m = hc.n_out < capacity ? hc.n_out : capacity;
     if (m > 0) {
         HIPCHK(hipMemcpy(out, o.p, (size_t)m * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out_scale, oa.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < m; i++) out_scale[i] &= 0xff;
     }
     *n_out = m;
     return SIFTMI_OK;
@@ -927,12 +976,20 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
     DevBuf b, k, ks, r;
     if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = k.upload(kps, (size_t)n * 16)) || (rc = ks.upload(kp_scale, (size_t)n * 4)) ||
         (rc = r.alloc((size_t)n * sizeof(KpRecord)))) return rc;
-    BlurPlanes bp;
-    for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
-    if (n > 0)
-        hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(256), 0, 0, bp, W, H, octsize,
-                           (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
+    int oct = 0;
+    while ((1 << oct) < octsize && oct < SIFT_MAX_OCTAVES - 1) oct++;
+    if ((1 << oct) != octsize) return fail(SIFTMI_EINVAL, "octsize must be a power of two");
+    OctaveTable tab;
+    memset(&tab, 0, sizeof tab);
+    tab.base = b.as<float>(); tab.off[oct] = 0; tab.W[oct] = W; tab.H[oct] = H;
+    std::vector<int32_t> aux((size_t)n);
+    for (int64_t i = 0; i < n; i++) aux[(size_t)i] = kp_scale[i] | (oct << 8);
+    if (n > 0) {
+        HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(256), 0, 0, tab,
+                           (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (Counters *)nullptr, 0, 0, (int)n,
                            (int)n, r.as<KpRecord>());
+    }
     if ((rc = stage_end())) return rc;
     std::vector<KpRecord> h((size_t)n);
     if (n > 0) HIPCHK(hipMemcpy(h.data(), r.p, (size_t)n * sizeof(KpRecord), hipMemcpyDeviceToHost));

@@ -87,6 +87,10 @@ int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 int siftmi_plan_keypoints(siftmi_plan *plan, const void *image, int32_t image_dtype, int32_t image_is_device,
                           siftmi_keypoint *out, int32_t out_is_device, int64_t capacity, int64_t *n_out,
                           int32_t *overflow);
+/* two-step variant: siftmi_plan_keypoints(..., out = NULL, capacity = 0, ...) only returns the count and
+ * leaves the records on the device; siftmi_plan_fetch copies records [first, first+count) of the last call
+ * (to a host buffer, or to a device buffer with out_is_device) -- saves one host-side copy of the result */
+int siftmi_plan_fetch(siftmi_plan *plan, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count);
 int siftmi_plan_get_minmax(const siftmi_plan *plan, float *min_out, float *max_out);
 int siftmi_plan_profile(const siftmi_plan *plan, char *buf, int64_t buflen);
 /* device time (ms, hipEvent on the plan's stream) of the kernels of the last keypoints() call,

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "siftmi_plan_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "siftmi_plan_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "siftmi_plan_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),
     "siftmi_plan_get_minmax": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "siftmi_plan_profile": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "siftmi_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -129,6 +129,7 @@ struct siftmi_plan {
     size_t n_events = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     float last_min = 0, last_max = 0;
+    int64_t last_count = 0;
     std::vector<void *> allocs;
 
     template <class T> int alloc(T **p, size_t nbytes) {
@@ -577,16 +578,32 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     int ovf = hc.overflow;
     if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
     int rc = SIFTMI_OK;
-    if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "output capacity too small; result truncated"; }
-    if (n > 0) {
-        HIPCHK(hipMemcpyAsync(out, p->records, (size_t)n * sizeof(KpRecord),
-                              out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, fin));
-        HIPCHK(hipStreamSynchronize(fin));
+    p->last_count = n;
+    if (out == nullptr && capacity == 0) {
+        // count-only call: the records stay on the device until siftmi_plan_fetch()
+    } else {
+        if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "output capacity too small; result truncated"; }
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(out, p->records, (size_t)n * sizeof(KpRecord),
+                                  out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, fin));
+            HIPCHK(hipStreamSynchronize(fin));
+        }
     }
     *n_out = n;
     if (overflow) *overflow = ovf;
     if (htime) fprintf(stderr, "[siftmi] enqueue %.0f us, wait %.0f us, records copy %.0f us\n", t_enq - t_enter, t_sync - t_enq, tnow() - t_sync);
     return rc;
+}
+
+int siftmi_plan_fetch(siftmi_plan *p, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count) {
+    if (!p || (count > 0 && !out)) return fail(SIFTMI_EINVAL, "null argument");
+    if (first < 0 || count < 0 || first + count > p->last_count) return fail(SIFTMI_EINVAL, "record range out of bounds");
+    if (count == 0) return SIFTMI_OK;
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(out, p->records + first, (size_t)count * sizeof(KpRecord),
+                          out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return SIFTMI_OK;
 }
 
 int siftmi_plan_get_minmax(const siftmi_plan *p, float *mn, float *mx) {

@@ -142,12 +142,12 @@ class SiftPlan(object):
         if L.siftmi_device_count() < 1:
             raise RuntimeError("sift_pyocl_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
         self._params = self._current_params()
+        self._par_key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
         _lib.check(L.siftmi_plan_create(self.shape[0], self.shape[1], self._code, self.device,
                                         C.byref(self._params), self._profile_level, C.byref(self._handle)))
         nbytes = C.c_int64()
         _lib.check(L.siftmi_plan_info(self._handle, None, None, C.byref(nbytes)))
         self.memory = int(nbytes.value)
-        self._out = numpy.empty(self.kpsize, dtype=self.dtype_kp)
         self.overflow = False
         self.debug = []
 
@@ -235,21 +235,25 @@ class SiftPlan(object):
             else:
                 raise RuntimeError("invalid input format error (%s)" % (str(self.dtype)))
             L = _lib.lib()
-            params = self._current_params()
-            if bytes(params) != bytes(self._params):
+            key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
+            if key != self._par_key:                 # `par` is read at call time, as in the reference
+                params = self._current_params()
                 _lib.check(L.siftmi_plan_set_params(self._handle, C.byref(params)))
-                self._params = params
+                self._params, self._par_key = params, key
             n = C.c_int64(0)
             ovf = C.c_int32(0)
-            rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, self._out.ctypes.data, 0,
-                                         self._out.size, C.byref(n), C.byref(ovf))
-            _lib.check(rc, allow=(_lib.ECAPACITY,))
-            self.overflow = bool(ovf.value) or rc == _lib.ECAPACITY
+            # count first (records stay on the device), then fetch straight into an exactly sized array
+            _lib.check(L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, None, 0, 0, C.byref(n), C.byref(ovf)))
+            self.overflow = bool(ovf.value)
             if self.overflow:
                 logger.warning("Keypoint counter overflow: more than %s keypoints, result truncated", self.kpsize)
-            output = self._out[:n.value].copy().view(numpy.recarray)
+            output = numpy.empty(n.value, dtype=self.dtype_kp)
+            if n.value:
+                _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, n.value))
+            output = output.view(numpy.recarray)
             del keep
-            logger.info("Execution time: %.3fms" % (1000 * (time.time() - t0)))
+            if logger.isEnabledFor(logging.INFO):
+                logger.info("Execution time: %.3fms" % (1000 * (time.time() - t0)))
         return output
 
     __call__ = keypoints

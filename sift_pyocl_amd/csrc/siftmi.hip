@@ -81,7 +81,7 @@ int kernel_size(double sigma) {   // utils.py:54-64 with odd=True, cutoff=4
 
 struct Taps { int n = 0; float t[64] = {0}; float *dev = nullptr; };
 
-struct Event { std::string label; hipEvent_t a = nullptr, b = nullptr; bool is_blur = false; double pixels = 0; int octave = -1; };
+struct Event { std::string label; hipEvent_t a = nullptr, b = nullptr; bool is_blur = false; double pixels = 0; int octave = -1; int launches = 1; };
 
 size_t dtype_size(int dt) {
     switch (dt) {
@@ -242,7 +242,7 @@ struct Scope {   // optional hipEvent bracket around one launch (profile=1: blur
     siftmi_plan *p; size_t idx = (size_t)-1; hipStream_t st;
     Scope(siftmi_plan *pl, const char *label, bool is_blur = false, double pixels = 0, hipStream_t s = nullptr, int octave = -1) : p(pl) {
         st = s ? s : p->stream;
-        if (!p->profile || (p->profile == 1 && !is_blur)) return;
+        if (!p->profile || (p->profile == 1 && !(is_blur && octave == 0))) return;
         if (p->n_events == p->events.size()) {
             Event e;
             hipEventCreate(&e.a); hipEventCreate(&e.b);
@@ -250,7 +250,7 @@ struct Scope {   // optional hipEvent bracket around one launch (profile=1: blur
         }
         idx = p->n_events++;
         Event &e = p->events[idx];
-        e.label = label; e.is_blur = is_blur; e.pixels = pixels; e.octave = octave;
+        e.label = label; e.is_blur = is_blur; e.pixels = pixels; e.octave = octave; e.launches = 1;
         hipEventRecord(e.a, st);
     }
     ~Scope() { if (idx != (size_t)-1) hipEventRecord(p->events[idx].b, st); }
@@ -529,10 +529,19 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     // one event per octave.
     for (int oct = 0; oct < p->n_oct; oct++) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
-        for (int s = 0; s < 5; s++) {
-            snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
-            Scope sc(p, lab, true, (double)W * H, nullptr, oct);
-            launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
+        if (p->profile == 1) {
+            // light profiling: ONE event pair around the five back-to-back blur launches of octave 0 (event
+            // records between kernels cost ~4 us each and keep consecutive launches from overlapping)
+            Scope *chain = (oct == 0) ? new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0) : nullptr;
+            if (chain && chain->idx != (size_t)-1) p->events[chain->idx].launches = 5;
+            for (int s = 0; s < 5; s++) launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
+            delete chain;
+        } else {
+            for (int s = 0; s < 5; s++) {
+                snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
+                Scope sc(p, lab, true, (double)W * H, nullptr, oct);
+                launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
+            }
         }
         if (oct < p->n_oct - 1) {
             const int SW = p->ow[(size_t)oct + 1], SH = p->oh[(size_t)oct + 1];
@@ -645,7 +654,7 @@ int siftmi_plan_blur_ms(const siftmi_plan *p, int32_t octave, float *blur_ms, in
         if (p->events[i].is_blur && (octave < 0 || p->events[i].octave == octave)) {
             float ms = 0;
             hipEventElapsedTime(&ms, p->events[i].a, p->events[i].b);
-            bms += ms; bl++; px += p->events[i].pixels;
+            bms += ms; bl += p->events[i].launches; px += p->events[i].pixels;
         }
     if (blur_ms) *blur_ms = bms;
     if (blur_launches) *blur_launches = bl;

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const float *__restrict__ 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int N> struct MarchGeom {
-    static constexpr int TX = 256;
+template <int N, int NT = 128> struct MarchGeom {
+    static constexpr int TX = 2 * NT;                        // 2 columns per thread
     static constexpr int C = (N & 1) ? N / 2 : N / 2 - 1;
     static constexpr int NP = (N + 1) / 2;                   // row pairs per block
     static constexpr int COLS = TX + N - 1;
@@ -231,18 +231,18 @@ template <int N> struct MarchGeom {
     static constexpr int NW = (N + 3 + 1) & ~1;              // columns read per 4-output H task (even)
     static constexpr int LDS_BYTES = NP * PITCH * 2 * 4;
     static constexpr int HALO = N - 1;                       // columns beyond the first 256
-    static constexpr int NB = (NP * HALO + 127) / 128;       // halo pair-elements per thread
+    static constexpr int NB = (NP * HALO + NT - 1) / NT;      // halo pair-elements per thread
 };
 
-template <int N, bool NORM>
-__global__ __launch_bounds__(128) void blur_march_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                         int W, int H, int nblocks, TapsArg<N> taps,
-                                                         const uint32_t *__restrict__ mm) {
-    using G = MarchGeom<N>;
+template <int N, bool NORM, int NT>
+__global__ __launch_bounds__(NT) void blur_march_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        int W, int H, int nblocks, TapsArg<N> taps,
+                                                        const uint32_t *__restrict__ mm) {
+    using G = MarchGeom<N, NT>;
     static_assert(N & 1, "marching blur needs an odd tap count");
     extern __shared__ float4 smem4[];
     float *s = reinterpret_cast<float *>(smem4);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int x0 = blockIdx.x * G::TX;
     const int rows_out = nblocks * N - (N - 1);
     const int ys = blockIdx.y * rows_out;            // first output row of this segment
@@ -250,15 +250,15 @@ __global__ __launch_bounds__(128) void blur_march_kernel(const float *__restrict
     float mn = 0.f, range = 1.f;
     if (NORM) { mn = ord2f(mm[0]); range = ord2f(mm[1]) - mn; }
 
-    // staging duty of this thread: columns tid and tid+128 of every row, plus NB halo pair-elements
+    // staging duty of this thread: columns tid and tid+NT of every row, plus NB halo pair-elements
     const int gx_a = reflect_index(x0 - G::C + tid, W);
-    const int gx_b = reflect_index(x0 - G::C + 128 + tid, W);
+    const int gx_b = reflect_index(x0 - G::C + NT + tid, W);
     int hb_rp[G::NB], hb_col[G::NB], hb_gx[G::NB];
 #pragma unroll
     for (int u = 0; u < G::NB; u++) {
-        const int e = tid + 128 * u;
+        const int e = tid + NT * u;
         hb_rp[u] = (e < G::NP * G::HALO) ? e / G::HALO : -1;
-        hb_col[u] = 256 + e % G::HALO;
+        hb_col[u] = G::TX + e % G::HALO;
         hb_gx[u] = reflect_index(x0 - G::C + hb_col[u], W);
     }
 
@@ -314,16 +314,18 @@ __global__ __launch_bounds__(128) void blur_march_kernel(const float *__restrict
 #pragma unroll
         for (int rp = 0; rp < G::NP; rp++) {
             *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + tid) * 2) = norm2(pa[rp]);
-            *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + 128 + tid) * 2) = norm2(pb[rp]);
+            *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + NT + tid) * 2) = norm2(pb[rp]);
         }
 #pragma unroll
         for (int u = 0; u < G::NB; u++)
             if (hb_rp[u] >= 0) *reinterpret_cast<f32x2 *>(s + (hb_rp[u] * G::PITCH + hb_col[u]) * 2) = norm2(ph[u]);
         __syncthreads();
         if (blk + 1 < nblocks) prefetch(blk + 1);
-        // ---- horizontal pass in place: wave w takes row pairs w, w+2, ...; lane owns 4 columns
-        for (int rp = wave; rp < G::NP; rp += 2) {
-            float *rowp = s + (rp * G::PITCH + 4 * lane) * 2;
+        // ---- horizontal pass in place: a task = 4 consecutive columns of one row pair; the NT/2 tasks of a
+        //      row pair are consecutive lanes of one wave (a whole wave for NT = 128, half a wave for NT = 64)
+        for (int task = tid; task < G::NP * (NT / 2); task += NT) {
+            const int rp = task / (NT / 2), t4 = task % (NT / 2);
+            float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
             // sliding window streamed through registers: b128 loads run PRE ahead of their first use
             f32x2 w[G::NW];
             constexpr int PRE = 4;

@@ -183,21 +183,29 @@ void launch_blur_t(hipStream_t st, const float *in, float *out, int W, int H, co
     hipLaunchKernelGGL((blur_hv_kernel<N, NORM>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
 }
 
-template <int N, bool NORM>
-void launch_march_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
-    using G = MarchGeom<N>;
+template <int N, bool NORM, int NT>
+void launch_march_nt(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+    using G = MarchGeom<N, NT>;
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     const int gx = (W + G::TX - 1) / G::TX;
-    // pick the segment height: enough workgroups to fill 256 CUs twice, warm-up overhead (N-1)/rows kept low
-    int want_segments = (1024 + gx - 1) / gx;
+    // pick the segment height: enough workgroups to fill 256 CUs, warm-up overhead (N-1)/rows kept low
+    static const int want_wgs = getenv("SIFTMI_MARCH_WGS") ? atoi(getenv("SIFTMI_MARCH_WGS")) : 1024 * 128 / NT;
+    int want_segments = (want_wgs + gx - 1) / gx;
     int rows = (H + want_segments - 1) / want_segments;
     int nblocks = (rows + (N - 1) + N - 1) / N;
     if (nblocks < 3) nblocks = 3;
     if (const char *e = getenv("SIFTMI_MARCH_NB")) nblocks = atoi(e);   // dev tuning knob
     const int rows_out = nblocks * N - (N - 1);
     dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
-    hipLaunchKernelGGL((blur_march_kernel<N, NORM>), grid, dim3(128), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+    hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+}
+
+template <int N, bool NORM>
+void launch_march_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+    static const int nt = getenv("SIFTMI_MARCH_NT") ? atoi(getenv("SIFTMI_MARCH_NT")) : 128;   // dev knob: 64 = one wave per workgroup
+    if (nt == 64) launch_march_nt<N, NORM, 64>(st, in, out, W, H, taps, mm);
+    else launch_march_nt<N, NORM, 128>(st, in, out, W, H, taps, mm);
 }
 
 // returns false when no tiled instantiation exists for this tap count

@@ -8,10 +8,10 @@ import sift_pyocl_amd as sp
 
 nplans = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-size = 4096
+size = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 imgs = [torch.from_numpy(np.random.default_rng(i).random((size, size), dtype=np.float32)).cuda() for i in range(8)]
 torch.cuda.synchronize()
-plans = [sp.SiftPlan(shape=(size, size), dtype=np.float32, octave_max=3) for _ in range(nplans)]
+plans = [sp.SiftPlan(shape=(size, size), dtype=np.float32, octave_max=(3 if size >= 4096 else None)) for _ in range(nplans)]
 for p in plans:
     for i in range(2): p.keypoints(imgs[i])
 counts = [0] * nplans

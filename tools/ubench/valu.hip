@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void kpk(float *out, float s0, float s1) {
 int main() {
     float *d; hipMalloc(&d, 4096 * 256 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 4; mode++) for (int blocks : {1024, 2048, 4096}) {
+    for (int mode = 0; mode < 4; mode++) for (int blocks : {256, 512, 1024, 2048, 4096}) {
         float ms = 0;
         for (int rep = 0; rep < 3; rep++) {
             hipEventRecord(e0);

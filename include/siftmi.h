@@ -91,6 +91,20 @@ int siftmi_plan_keypoints(siftmi_plan *plan, const void *image, int32_t image_dt
  * leaves the records on the device; siftmi_plan_fetch copies records [first, first+count) of the last call
  * (to a host buffer, or to a device buffer with out_is_device) -- saves one host-side copy of the result */
 int siftmi_plan_fetch(siftmi_plan *plan, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count);
+/* Affine warp with bilinear interpolation of an image of the plan's shape -- the `transform` / `transform_RGB`
+ * kernels (openCL/transform.cl:22, :116) as LinearAlign.align launches them (sift-src/alignment.py:325-348).
+ *   out[y][x] = bilinear(image, (ty, tx)),  ty = matrix[0]*y + matrix[1]*x + offset[0],
+ *                                           tx = matrix[2]*y + matrix[3]*x + offset[1]
+ * with `fill` outside the image, for taps right of / below it, and where tx >= W-0.5 or ty >= H-0.5.
+ *   image        H x W float32 (channels 1) or H x W x 3 uint8 (channels 3); NULL = the host image most recently
+ *                handed to siftmi_plan_keypoints, still staged on the device (the reference's buffers["input"])
+ *   out          OH x OW (x3) of the same element type; the whole output is written (the reference only
+ *                launches W x H work-items and leaves the `extra` margin of its output buffer undefined)
+ *   mode         1 = bilinear (the only value the reference passes), else nearest-lower tap
+ *   kernel_ms    optional, hipEvent duration of the kernel */
+int siftmi_plan_transform(siftmi_plan *plan, const void *image, int32_t image_is_device, int32_t channels, void *out,
+                          int32_t out_is_device, int32_t out_width, int32_t out_height, const float *matrix /*[4]*/,
+                          const float *offset /*[2]*/, float fill, int32_t mode, double *kernel_ms);
 int siftmi_plan_get_minmax(const siftmi_plan *plan, float *min_out, float *max_out);
 int siftmi_plan_profile(const siftmi_plan *plan, char *buf, int64_t buflen);
 /* device time (ms, hipEvent on the plan's stream) of the kernels of the last keypoints() call,

@@ -215,3 +215,23 @@ def match(kp1, kp2, ratio_th=np.float32(0.73 * 0.73), cap=None):
 
 def octave_count(H, W):
     return lib().so_octave_count(C.c_int(H), C.c_int(W))
+
+
+def transform(image, matrix, offset, out_shape=None, fill=0.0, mode=1):
+    """transform.cl restated (float32 image, or uint8 RGB)."""
+    matrix = _f32(matrix).reshape(4); offset = _f32(offset).reshape(2)
+    if image.ndim == 3:
+        image = np.ascontiguousarray(image, np.uint8)
+        H, W = image.shape[:2]
+        OH, OW = out_shape or (H, W)
+        out = np.empty((OH, OW, 3), np.uint8)
+        lib().so_transform_rgb(_p(image), _p(out), _p(matrix), _p(offset), C.c_int(W), C.c_int(H), C.c_int(OW), C.c_int(OH),
+                               C.c_float(fill), C.c_int(mode))
+        return out
+    image = _f32(image)
+    H, W = image.shape
+    OH, OW = out_shape or (H, W)
+    out = np.empty((OH, OW), np.float32)
+    lib().so_transform(_p(image), _p(out), _p(matrix), _p(offset), C.c_int(W), C.c_int(H), C.c_int(OW), C.c_int(OH),
+                       C.c_float(fill), C.c_int(mode))
+    return out

@@ -246,3 +246,23 @@ def match(kp1, kp2, ratio=None, cap=None):
                        C.c_int(kp2.size), C.c_int(kp1.size))
     n = int(cnt[0])
     return out[:min(n, cap)].copy(), n
+
+
+def transform(image, matrix, offset, out_shape=None, fill=0.0, mode=1):
+    """transform / transform_RGB of transform.cl run natively (launch as alignment.py:336-346)."""
+    matrix = np.ascontiguousarray(matrix, np.float32).reshape(4); offset = np.ascontiguousarray(offset, np.float32).reshape(2)
+    if image.ndim == 3:
+        image = np.ascontiguousarray(image, np.uint8)
+        H, W = image.shape[:2]
+        OH, OW = out_shape or (H, W)
+        out = np.zeros((OH, OW, 3), np.uint8)
+        lib().ref_transform_RGB(_p(image), _p(out), _p(matrix), _p(offset), C.c_int(W), C.c_int(H), C.c_int(OW), C.c_int(OH),
+                                C.c_float(fill), C.c_int(mode))
+        return out
+    image = np.ascontiguousarray(image, np.float32)
+    H, W = image.shape
+    OH, OW = out_shape or (H, W)
+    out = np.zeros((OH, OW), np.float32)
+    lib().ref_transform(_p(image), _p(out), _p(matrix), _p(offset), C.c_int(W), C.c_int(H), C.c_int(OW), C.c_int(OH),
+                        C.c_float(fill), C.c_int(mode))
+    return out

@@ -53,6 +53,8 @@ float cl_rsqrt(float x) __asm__("_Z5rsqrtf");   float cl_rsqrt(float x) { return
 float cl_atan2(float y, float x) __asm__("_Z5atan2ff"); float cl_atan2(float y, float x) { return atan2f(y, x); }
 float cl_fmax(float a, float b) __asm__("_Z4fmaxff"); float cl_fmax(float a, float b) { return fmaxf(a, b); }
 float cl_fmin(float a, float b) __asm__("_Z4fminff"); float cl_fmin(float a, float b) { return fminf(a, b); }
+typedef float cl_float2 __attribute__((vector_size(8)));
+float cl_dot2(cl_float2 a, cl_float2 b) __asm__("_Z3dotDv2_fS_"); float cl_dot2(cl_float2 a, cl_float2 b) { return a[0] * b[0] + a[1] * b[1]; }
 unsigned cl_minu(unsigned a, unsigned b) __asm__("_Z3minjj"); unsigned cl_minu(unsigned a, unsigned b) { return a < b ? a : b; }
 
 // ---- the reference kernels (symbols defined by the .cl objects) ----------------------------
@@ -77,6 +79,8 @@ void orientation_assignment(void *kps, float *grad, float *ori, int *counter, in
 void descriptor(void *kps, unsigned char *desc, float *grad, float *ori, int octsize, int start,
                 int *end, int W, int H);
 void matching(void *k1, void *k2, void *matchings, int *counter, int max_nb, float ratio, int size1, int size2);
+void transform(float *image, float *output, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode);
+void transform_RGB(unsigned char *image, unsigned char *output, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode);
 }
 
 namespace {
@@ -164,6 +168,15 @@ void ref_descriptor(void *kps, unsigned char *desc, float *grad, float *ori, int
 }
 void ref_matching(void *k1, void *k2, void *matchings, int *counter, int max_nb, float ratio, int n1, int n2, int nitems) {
     run1d((size_t)nitems, [&] { matching(k1, k2, matchings, counter, max_nb, ratio, n1, n2); });
+}
+
+void ref_transform(float *image, float *out, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode) {
+    run2d((size_t)OW, (size_t)OH, [&] { transform(image, out, matrix, offset, W, H, OW, OH, fill, mode); });
+}
+void ref_transform_RGB(unsigned char *image, unsigned char *out, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode) {
+    for (size_t y = 0; y < (size_t)OH; y++)
+        for (size_t x = 0; x < (size_t)OW; x++)
+            for (size_t c = 0; c < 4; c++) { t_gid[0] = c; t_gid[1] = x; t_gid[2] = y; transform_RGB(image, out, matrix, offset, W, H, OW, OH, fill, mode); }
 }
 
 }  // extern "C"

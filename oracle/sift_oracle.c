@@ -622,3 +622,69 @@ int64_t so_match(const so_record *k1, int64_t n1, const so_record *k2, int64_t n
     free(best);
     return count;
 }
+
+/* ------------------------------------------------------------------ affine warp  (transform.cl:22-110, 116-204)
+ * out[y][x] = bilinear(image, M*(y,x) + off) with the reference's quirks: (y,x) order of the matrix rows
+ * ("Fortran convention"), reads guarded by fill at the right/bottom edge, and the final half-pixel cut.
+ * matrix = {m0,m1,m2,m3}: ty = m0*y + m1*x + off[0];  tx = m2*y + m3*x + off[1]. */
+static inline float so_transform_sample(float tx, float ty, int W, int H, float fill, int mode,
+                                        float p, float px, float py, float pn) {
+    (void)H; (void)W; (void)mode; (void)fill;
+    const int tx_prev = (int)tx, tx_next = tx_prev + 1, ty_prev = (int)ty, ty_next = ty_prev + 1;
+    const float i1 = ((float)tx_next - tx) * p + (tx - (float)tx_prev) * px;
+    const float i2 = ((float)tx_next - tx) * py + (tx - (float)tx_prev) * pn;
+    return ((float)ty_next - ty) * i1 + (ty - (float)ty_prev) * i2;
+}
+
+void so_transform(const float *image, float *out, const float *matrix, const float *offset, int W, int H,
+                  int OW, int OH, float fill, int mode) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < OH; y++)
+        for (int x = 0; x < OW; x++) {
+            float tx = matrix[2] * (float)y + matrix[3] * (float)x;
+            float ty = matrix[0] * (float)y + matrix[1] * (float)x;
+            tx += offset[1]; ty += offset[0];
+            float interp = fill;
+            if (0.0f <= tx && tx < (float)W && 0.0f <= ty && ty < (float)H) {
+                const int tx_prev = (int)tx, tx_next = tx_prev + 1, ty_prev = (int)ty, ty_next = ty_prev + 1;
+                if (mode == 1) {
+                    const float p = image[(size_t)ty_prev * W + tx_prev];
+                    const float px = tx_next >= W ? fill : image[(size_t)ty_prev * W + tx_next];
+                    const float py = ty_next >= H ? fill : image[(size_t)ty_next * W + tx_prev];
+                    const float pn = (tx_next >= W || ty_next >= H) ? fill : image[(size_t)ty_next * W + tx_next];
+                    interp = so_transform_sample(tx, ty, W, H, fill, mode, p, px, py, pn);
+                } else interp = image[(size_t)ty_prev * W + tx_prev];
+            }
+            if (tx >= (float)W + -0.5f) interp = fill;
+            if (ty >= (float)H + -0.5f) interp = fill;
+            out[(size_t)y * OW + x] = interp;
+        }
+}
+
+void so_transform_rgb(const uint8_t *image, uint8_t *out, const float *matrix, const float *offset, int W, int H,
+                      int OW, int OH, float fill, int mode) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < OH; y++)
+        for (int x = 0; x < OW; x++) {
+            float tx = matrix[2] * (float)y + matrix[3] * (float)x;
+            float ty = matrix[0] * (float)y + matrix[1] * (float)x;
+            tx += offset[1]; ty += offset[0];
+            const int inside = (0.0f <= tx && tx < (float)W && 0.0f <= ty && ty < (float)H);
+            const int tx_prev = (int)tx, tx_next = tx_prev + 1, ty_prev = (int)ty, ty_next = ty_prev + 1;
+            for (int c = 0; c < 3; c++) {
+                float interp = fill;
+                if (inside) {
+                    if (mode == 1) {
+                        const float p = (float)image[3 * ((size_t)ty_prev * W + tx_prev) + c];
+                        const float px = tx_next >= W ? fill : (float)image[3 * ((size_t)ty_prev * W + tx_next) + c];
+                        const float py = ty_next >= H ? fill : (float)image[3 * ((size_t)ty_next * W + tx_prev) + c];
+                        const float pn = (tx_next >= W || ty_next >= H) ? fill : (float)image[3 * ((size_t)ty_next * W + tx_next) + c];
+                        interp = so_transform_sample(tx, ty, W, H, fill, mode, p, px, py, pn);
+                    } else interp = (float)image[3 * ((size_t)ty_prev * W + tx_prev) + c];
+                }
+                if (tx >= (float)W + -0.5f) interp = fill;
+                if (ty >= (float)H + -0.5f) interp = fill;
+                out[3 * ((size_t)y * OW + x) + c] = (uint8_t)interp;
+            }
+        }
+}

@@ -19,6 +19,7 @@
 #include "../../include/siftmi.h"
 #include "k_extrema.hpp"
 #include "k_keypoint.hpp"
+#include "k_align.hpp"
 #include "k_match.hpp"
 #include "k_pyramid.hpp"
 #include "siftmath.hpp"
@@ -114,6 +115,10 @@ struct siftmi_plan {
     bool overlap = true;
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
     void *raw = nullptr;          // host-input staging (any dtype)
+    int raw_dtype = -1;           // dtype of the image currently staged in `raw` (-1: none)
+    void *warp_in = nullptr, *warp_out = nullptr;   // siftmi_plan_transform staging, grown on demand
+    size_t warp_in_bytes = 0, warp_out_bytes = 0;
+    hipEvent_t ev_wa = nullptr, ev_wb = nullptr;
     float *conv = nullptr;        // converted f32 input when dtype != f32
     uint32_t *mm = nullptr;
     Counters *cnt = nullptr;
@@ -443,6 +448,10 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
+    if (p->warp_in) hipFree(p->warp_in);
+    if (p->warp_out) hipFree(p->warp_out);
+    if (p->ev_wa) hipEventDestroy(p->ev_wa);
+    if (p->ev_wb) hipEventDestroy(p->ev_wb);
     for (Event &e : p->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (p->ev_first) hipEventDestroy(p->ev_first);
     if (p->ev_last) hipEventDestroy(p->ev_last);
@@ -486,6 +495,7 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     } else {
         HIPCHK(hipMemcpyAsync(p->raw, image, N * dtype_size(image_dtype), hipMemcpyHostToDevice, p->stream));
         src = p->raw;
+        p->raw_dtype = image_dtype;
     }
     const bool htime = getenv("SIFTMI_HOST_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -620,6 +630,69 @@ int siftmi_plan_fetch(siftmi_plan *p, siftmi_keypoint *out, int32_t out_is_devic
     HIPCHK(hipMemcpyAsync(out, p->records + first, (size_t)count * sizeof(KpRecord),
                           out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
+    return SIFTMI_OK;
+}
+
+// Affine warp of an image of the plan's shape (transform.cl:22,116; host side alignment.py:325-348).
+int siftmi_plan_transform(siftmi_plan *p, const void *image, int32_t image_is_device, int32_t channels, void *out,
+                          int32_t out_is_device, int32_t OW, int32_t OH, const float *matrix, const float *offset, float fill,
+                          int32_t mode, double *kernel_ms) {
+    if (!p || !out || !matrix || !offset) return fail(SIFTMI_EINVAL, "null argument");
+    if (channels != 1 && channels != 3) return fail(SIFTMI_EINVAL, "channels must be 1 (float32) or 3 (RGB8), got %d", channels);
+    if (OW < 0 || OH < 0) return fail(SIFTMI_EINVAL, "negative output shape");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t px = channels == 1 ? 4 : 3;
+    const size_t in_bytes = (size_t)p->W * p->H * px, out_bytes = (size_t)OW * OH * px;
+    const void *src = image;
+    if (!image) {
+        const int want = channels == 1 ? SIFTMI_F32 : SIFTMI_RGB8;
+        if (p->raw_dtype != want)
+            return fail(SIFTMI_EINVAL, "no staged input of the requested format (staged dtype %d, wanted %d)", p->raw_dtype, want);
+        src = p->raw;
+    } else if (image_is_device) {
+        HIPCHK(hipDeviceSynchronize());
+    } else {
+        if (p->warp_in_bytes < in_bytes) {
+            if (p->warp_in) hipFree(p->warp_in);
+            p->warp_in = nullptr; p->warp_in_bytes = 0;
+            hipError_t e = hipMalloc(&p->warp_in, in_bytes ? in_bytes : 16);
+            if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", in_bytes, hipGetErrorString(e));
+            p->warp_in_bytes = in_bytes;
+        }
+        HIPCHK(hipMemcpyAsync(p->warp_in, image, in_bytes, hipMemcpyHostToDevice, p->stream));
+        src = p->warp_in;
+    }
+    void *dst = out;
+    if (!out_is_device) {
+        if (p->warp_out_bytes < out_bytes) {
+            if (p->warp_out) hipFree(p->warp_out);
+            p->warp_out = nullptr; p->warp_out_bytes = 0;
+            hipError_t e = hipMalloc(&p->warp_out, out_bytes ? out_bytes : 16);
+            if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", out_bytes, hipGetErrorString(e));
+            p->warp_out_bytes = out_bytes;
+        }
+        dst = p->warp_out;
+    }
+    if (!p->ev_wa) { HIPCHK(hipEventCreate(&p->ev_wa)); HIPCHK(hipEventCreate(&p->ev_wb)); }
+    AffineArgs a{matrix[0], matrix[1], matrix[2], matrix[3], offset[0], offset[1], fill, mode};
+    if (OW > 0 && OH > 0) {
+        const int xcols = channels == 1 ? 64 : 256;   // RGB: 4 pixels per thread
+        const dim3 grid((unsigned)((OW + xcols - 1) / xcols), (unsigned)((OH + 3) / 4)), block(64, 4);
+        hipEventRecord(p->ev_wa, p->stream);
+        if (channels == 1)
+            hipLaunchKernelGGL(transform_kernel, grid, block, 0, p->stream, (const float *)src, (float *)dst, a, p->W, p->H, OW, OH);
+        else
+            hipLaunchKernelGGL(transform_rgb_kernel, grid, block, 0, p->stream, (const uint8_t *)src, (uint8_t *)dst, a, p->W, p->H, OW, OH);
+        hipEventRecord(p->ev_wb, p->stream);
+        if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dst, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    }
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    if (kernel_ms) {
+        float ms = 0;
+        if (OW > 0 && OH > 0) hipEventElapsedTime(&ms, p->ev_wa, p->ev_wb);
+        *kernel_ms = ms;
+    }
     return SIFTMI_OK;
 }
 

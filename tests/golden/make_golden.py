@@ -14,6 +14,8 @@ Fixtures (all inputs are regenerated from seeds by tests/util.py, only outputs a
   stages_131x97.npz   every intermediate of octaves 0 and 1 of a 131x97 smoothed-noise image
   kp_<name>.npz       final keypoints (sorted) of four synthetic images
   match.npz           match pairs of two 1500 / 1200 descriptor sets
+  transform.npz       affine warps (transform.cl) of a 97x131 float image and a 40x53 RGB image, cases of
+                      tests/util.py:TRANSFORM_CASES
 """
 import os
 import sys
@@ -26,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import pyref  # noqa: E402
-from util import multiscale_noise, rectangles, smooth_noise, sort_kp, sort_rows, white_noise, dtype_kp  # noqa: E402
+from util import TRANSFORM_CASES, transform_inputs, multiscale_noise, rectangles, smooth_noise, sort_kp, sort_rows, white_noise, dtype_kp  # noqa: E402
 
 FINAL_CASES = {"white512": (white_noise, (512, 512)), "smooth512": (smooth_noise, (512, 512)),
                "multi300x421": (multiscale_noise, (300, 421)), "rect257x511": (rectangles, (257, 511))}
@@ -76,6 +78,13 @@ def main():
     pairs, n = pyref.match(a, b)
     np.savez_compressed(os.path.join(HERE, "match.npz"), pairs=sort_rows(pairs), total=n)
     print("match pairs", n)
+    gray, rgb = transform_inputs()
+    out = {}
+    for i, (M, off, fill, mode, oshape) in enumerate(TRANSFORM_CASES):
+        out["gray%d" % i] = pyref.transform(gray, M, off, out_shape=oshape and tuple(s + e for s, e in zip(gray.shape, oshape)), fill=fill, mode=mode)
+        out["rgb%d" % i] = pyref.transform(rgb, M, off, out_shape=oshape and tuple(s + e for s, e in zip(rgb.shape[:2], oshape)), fill=fill, mode=mode)
+    np.savez_compressed(os.path.join(HERE, "transform.npz"), **out)
+    print("transform cases", len(TRANSFORM_CASES))
 
 
 if __name__ == "__main__":

@@ -152,3 +152,19 @@ def test_siftmath_against_mpmath(oracle):
         L.so_sincosf(C.c_float(x), C.byref(s), C.byref(c))
         assert np.float32(s.value) == np.float32(mp.nstr(mp.sin(mp.mpf(float(x))), 30))
         assert np.float32(c.value) == np.float32(mp.nstr(mp.cos(mp.mpf(float(x))), 30))
+
+
+def test_transform(oracle):
+    """transform / transform_RGB (openCL/transform.cl) cases of tests/util.py against the reference kernels' output."""
+    from util import TRANSFORM_CASES, transform_inputs
+    g = load("transform.npz")
+    gray, rgb = transform_inputs()
+    for i, (M, off, fill, mode, extra) in enumerate(TRANSFORM_CASES):
+        og = extra and tuple(s + e for s, e in zip(gray.shape, extra))
+        orgb = extra and tuple(s + e for s, e in zip(rgb.shape[:2], extra))
+        assert biteq(oracle.transform(gray, M, off, out_shape=og, fill=fill, mode=mode), g["gray%d" % i]), "gray case %d" % i
+        assert biteq(oracle.transform(rgb, M, off, out_shape=orgb, fill=fill, mode=mode), g["rgb%d" % i]), "rgb case %d" % i
+    # sanity on what the fixture says: a pure integer shift moves pixels exactly
+    M, off, fill, mode, _ = TRANSFORM_CASES[2]
+    out = g["gray2"]
+    assert np.array_equal(out[10:50, 0:100], gray[6:46, 6:106])

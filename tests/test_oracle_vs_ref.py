@@ -34,3 +34,19 @@ def test_match_identical(oracle, ref):
     p_o, n_o = oracle.match(k1, k2)
     p_r, n_r = ref.match(k1, k2, cap=len(k1))
     assert n_o == n_r and np.array_equal(sort_rows(p_o), sort_rows(p_r))
+
+
+def test_transform_identical(oracle, ref):
+    rng = np.random.default_rng(77)
+    img = (smooth_noise((150, 203), seed=78) * 1000.0 - 300.0).astype(np.float32)
+    rgb = rng.integers(0, 256, (64, 81, 3), dtype=np.uint8)
+    for k in range(12):
+        M = (np.eye(2) + rng.normal(0, 0.08, (2, 2))).astype(np.float32).reshape(4)
+        off = rng.normal(0, 12, 2).astype(np.float32)
+        fill = float(rng.integers(0, 200))
+        for mode in (1, 0):
+            a = oracle.transform(img, M, off, fill=fill, mode=mode); b = ref.transform(img, M, off, fill=fill, mode=mode)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, mode)
+            assert np.array_equal(oracle.transform(rgb, M, off, fill=fill, mode=mode), ref.transform(rgb, M, off, fill=fill, mode=mode))
+        a = oracle.transform(img, M, off, out_shape=(180, 230), fill=fill); b = ref.transform(img, M, off, out_shape=(180, 230), fill=fill)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

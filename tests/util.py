@@ -84,3 +84,23 @@ def compare_keypoints_libm(a, b, what="", ulp=2, max_bad_rows=0.01):
     assert bad <= max(2, max_bad_rows * len(a)), "%s: %d of %d rows differ" % (what, bad, len(a))
     return dict(rows=len(a), rows_differing=bad, scale_ulp=int(ds.max(initial=0)), angle_ulp=int(da.max(initial=0)),
                 desc_bins_differing=int((dd > 0).sum()))
+
+
+# (matrix[4], offset[2], fill, mode, extra (dy, dx) added to the output shape or None) -- transform.cl cases
+TRANSFORM_CASES = [
+    ([1, 0, 0, 1], [0, 0], 0.0, 1, None),                       # identity: last row / column cut to fill
+    ([1, 0, 0, 1], [3.25, -2.5], 7.0, 1, None),                 # pure shift, fractional
+    ([1, 0, 0, 1], [-4.0, 6.0], 1.5, 1, None),                  # integer shift
+    ([0.99, 0.02, -0.03, 1.01], [1.7, 4.2], 3.0, 1, None),      # small affine (the LinearAlign regime)
+    ([0.5, 0, 0, 0.5], [10, 10], 2.0, 1, None),                 # zoom in
+    ([1.3, 0.2, -0.1, 1.2], [-5.5, -7.25], 9.0, 1, None),       # zoom out: large fill area
+    ([0.0, 1.0, 1.0, 0.0], [0.0, 0.0], 4.0, 1, None),           # transpose
+    ([0.99, 0.02, -0.03, 1.01], [1.7, 4.2], 3.0, 0, None),      # nearest-lower mode
+    ([1, 0, 0, 1], [-8.5, -6.25], 5.0, 1, (17, 13)),            # output larger than the input (extra margin)
+]
+
+
+def transform_inputs():
+    gray = (smooth_noise((97, 131), seed=41, sigma=1.5) * 255.0).astype(np.float32)
+    rgb = np.random.default_rng(42).integers(0, 256, (40, 53, 3), dtype=np.uint8)
+    return gray, rgb

@@ -69,6 +69,111 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------
+// Typed pixel load: the integer / RGB converters of preprocess.cl:53-223 applied at the point of use, so that a
+// u8 / u16 / RGB frame is never materialised as an f32 plane in HBM.  DT = SIFTMI_* dtype code
+// (0 f32, 1 u8, 2 u16, 3 u32, 4 u64, 5 i32, 6 i64, 8 rgb8).  (float)x rounds to nearest even exactly like the
+// OpenCL implicit conversion; RGB is 0.299f*R + 0.587f*G + 0.114f*B left to right, unfused (preprocess.cl:221).
+template <int DT> __device__ __forceinline__ float load_px(const void *__restrict__ base, size_t i) {
+    if constexpr (DT == 0) return static_cast<const float *>(base)[i];
+    else if constexpr (DT == 1) return (float)static_cast<const uint8_t *>(base)[i];
+    else if constexpr (DT == 2) return (float)static_cast<const uint16_t *>(base)[i];
+    else if constexpr (DT == 3) return (float)static_cast<const uint32_t *>(base)[i];
+    else if constexpr (DT == 4) return (float)static_cast<const uint64_t *>(base)[i];
+    else if constexpr (DT == 5) return (float)static_cast<const int32_t *>(base)[i];
+    else if constexpr (DT == 6) return (float)static_cast<const int64_t *>(base)[i];
+    else {
+        static_assert(DT == 8, "unsupported pixel type");
+        const uint8_t *q = static_cast<const uint8_t *>(base) + 3 * i;
+        const float r = (float)q[0], g = (float)q[1], b = (float)q[2];
+        return (0.299f * r + 0.587f * g) + 0.114f * b;
+    }
+}
+
+// min / max of the converted values of a typed frame.  A lane consumes chunks of R 16-byte words (u8: 16 pixels,
+// u16: 8, 32-bit: 4, 64-bit: 4 in two words, RGB8: 16 pixels in three words), four chunks in flight per step;
+// the frame base must be 16-byte aligned (checked on the host).
+template <int DT> struct TypedChunk {
+    static constexpr int R = (DT == 8) ? 3 : ((DT == 4 || DT == 6) ? 2 : 1);      // uint4 words per chunk
+    static constexpr int PX = (DT == 1 || DT == 8) ? 16 : (DT == 2 ? 8 : 4);     // pixels per chunk
+};
+
+template <int DT>
+__device__ __forceinline__ void typed_chunk_minmax(const uint4 (&w)[TypedChunk<DT>::R], float &lo, float &hi) {
+    auto upd = [&](float v) { lo = fminf(lo, v); hi = fmaxf(hi, v); };
+    if constexpr (DT == 1) {
+        const uint32_t d[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) { upd((float)(d[q] & 0xff)); upd((float)((d[q] >> 8) & 0xff)); upd((float)((d[q] >> 16) & 0xff)); upd((float)(d[q] >> 24)); }
+    } else if constexpr (DT == 2) {
+        const uint32_t d[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) { upd((float)(d[q] & 0xffff)); upd((float)(d[q] >> 16)); }
+    } else if constexpr (DT == 3) {
+        upd((float)w[0].x); upd((float)w[0].y); upd((float)w[0].z); upd((float)w[0].w);
+    } else if constexpr (DT == 5) {
+        upd((float)(int32_t)w[0].x); upd((float)(int32_t)w[0].y); upd((float)(int32_t)w[0].z); upd((float)(int32_t)w[0].w);
+    } else if constexpr (DT == 4 || DT == 6) {
+        const uint64_t q[4] = {(uint64_t)w[0].x | ((uint64_t)w[0].y << 32), (uint64_t)w[0].z | ((uint64_t)w[0].w << 32),
+                               (uint64_t)w[1].x | ((uint64_t)w[1].y << 32), (uint64_t)w[1].z | ((uint64_t)w[1].w << 32)};
+#pragma unroll
+        for (int k = 0; k < 4; k++) upd(DT == 4 ? (float)q[k] : (float)(int64_t)q[k]);
+    } else {
+        const uint32_t d[12] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w, w[2].x, w[2].y, w[2].z, w[2].w};
+        auto byte = [&](int b) { return (float)((d[b >> 2] >> (8 * (b & 3))) & 0xff); };
+#pragma unroll
+        for (int k = 0; k < 16; k++) upd((0.299f * byte(3 * k) + 0.587f * byte(3 * k + 1)) + 0.114f * byte(3 * k + 2));
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void minmax_typed_kernel(const void *__restrict__ img, int64_t n, uint32_t *mm) {
+    using C = TypedChunk<DT>;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nchunks = n / C::PX;
+    const uint4 *img4 = static_cast<const uint4 *>(img);
+    int64_t k = i;
+    for (; k + 3 * stride < nchunks; k += 4 * stride) {
+        uint4 w[4][C::R];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int r = 0; r < C::R; r++) w[u][r] = img4[(k + u * stride) * C::R + r];
+#pragma unroll
+        for (int u = 0; u < 4; u++) typed_chunk_minmax<DT>(w[u], lo, hi);
+    }
+    for (; k < nchunks; k += stride) {
+        uint4 w[C::R];
+#pragma unroll
+        for (int r = 0; r < C::R; r++) w[r] = img4[k * C::R + r];
+        typed_chunk_minmax<DT>(w, lo, hi);
+    }
+    for (int64_t k2 = nchunks * C::PX + i; k2 < n; k2 += stride) {
+        const float v = load_px<DT>(img, (size_t)k2);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    __shared__ float slo[4], shi[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { slo[wave] = lo; shi[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+        if (lo <= hi) {
+            atomicMin(&mm[0], f2ord(lo));
+            atomicMax(&mm[1], f2ord(hi));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // integer / RGB inputs -> float plane  (preprocess.cl:53-223): (float)x per element,
 // RGB: 0.299f*R + 0.587f*G + 0.114f*B evaluated left to right.
 template <typename T>
@@ -114,8 +219,8 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
     return min(max(i, 0), n - 1);   // clamp only matters for lanes whose output is masked
 }
 
-template <int N, bool NORM>
-__global__ __launch_bounds__(256) void blur_hv_kernel(const float *__restrict__ in, float *__restrict__ out,
+template <int N, bool NORM, int DT = 0>
+__global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                       int W, int H, TapsArg<N> taps,
                                                       const uint32_t *__restrict__ mm) {
     using G = BlurGeom<N>;
@@ -132,7 +237,7 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const float *__restrict__ 
         const int row = idx / G::COLS, col = idx - row * G::COLS;
         const int gy = reflect_index(y0 - G::C + row, H);
         const int gx = reflect_index(x0 - G::C + col, W);
-        float v = in[(size_t)gy * W + gx];
+        float v = load_px<DT>(in, (size_t)gy * W + gx);
         if (NORM) v = 255.0f * (v - mn) / range;     // preprocess.cl:250
         s[row * G::PITCH + col] = v;
     }
@@ -234,8 +339,8 @@ template <int N, int NT = 128> struct MarchGeom {
     static constexpr int NB = (NP * HALO + NT - 1) / NT;      // halo pair-elements per thread
 };
 
-template <int N, bool NORM, int NT>
-__global__ __launch_bounds__(NT) void blur_march_kernel(const float *__restrict__ in, float *__restrict__ out,
+template <int N, bool NORM, int NT, int DT = 0>
+__global__ __launch_bounds__(NT) void blur_march_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                         int W, int H, int nblocks, TapsArg<N> taps,
                                                         const uint32_t *__restrict__ mm) {
     using G = MarchGeom<N, NT>;
@@ -263,7 +368,11 @@ __global__ __launch_bounds__(NT) void blur_march_kernel(const float *__restrict_
     }
 
     // 32-bit byte offsets from the (scalar) plane base keep each load's address in one VGPR
-    auto ld = [&](unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + byte_off); };
+    // (typed frames: the same offset / 4 is the pixel index handed to the converter)
+    auto ld = [&](unsigned byte_off) {
+        if constexpr (DT == 0) return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + byte_off);
+        else return load_px<DT>(in, (size_t)(byte_off >> 2));
+    };
     const unsigned W4 = (unsigned)W * 4u;
     auto norm2 = [&](f32x2 v) {
         if (NORM) { v.x = 255.0f * (v.x - mn) / range; v.y = 255.0f * (v.y - mn) / range; }   // preprocess.cl:250
@@ -430,12 +539,13 @@ __global__ void shrink_kernel(const float *__restrict__ in, float *__restrict__ 
 }
 
 // normalise only (stage replay of preprocess.cl:239-252)
-__global__ void normalize_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n,
+template <int DT = 0>
+__global__ void normalize_kernel(const void *__restrict__ in, float *__restrict__ out, int64_t n,
                                  const uint32_t *__restrict__ mm) {
     const float mn = ord2f(mm[0]), range = ord2f(mm[1]) - mn;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = 255.0f * (in[i] - mn) / range;
+        out[i] = 255.0f * (load_px<DT>(in, (size_t)i) - mn) / range;
 }
 
 }  // namespace siftk

@@ -179,17 +179,17 @@ int compute_schedule(siftmi_plan *p) {
     return SIFTMI_OK;
 }
 
-template <int N, bool NORM>
-void launch_blur_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+template <int N, bool NORM, int DT = 0>
+void launch_blur_t(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
     using G = BlurGeom<N>;
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     dim3 grid((unsigned)((W + G::TX - 1) / G::TX), (unsigned)((H + G::TY - 1) / G::TY));
-    hipLaunchKernelGGL((blur_hv_kernel<N, NORM>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
+    hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
 }
 
-template <int N, bool NORM, int NT>
-void launch_march_nt(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+template <int N, bool NORM, int NT, int DT = 0>
+void launch_march_nt(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
     using G = MarchGeom<N, NT>;
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
@@ -203,14 +203,14 @@ void launch_march_nt(hipStream_t st, const float *in, float *out, int W, int H, 
     if (const char *e = getenv("SIFTMI_MARCH_NB")) nblocks = atoi(e);   // dev tuning knob
     const int rows_out = nblocks * N - (N - 1);
     dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
-    hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+    hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT, DT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
 }
 
 template <int N, bool NORM>
 void launch_march_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
     static const int nt = getenv("SIFTMI_MARCH_NT") ? atoi(getenv("SIFTMI_MARCH_NT")) : 128;   // dev knob: 64 = one wave per workgroup
-    if (nt == 64) launch_march_nt<N, NORM, 64>(st, in, out, W, H, taps, mm);
-    else launch_march_nt<N, NORM, 128>(st, in, out, W, H, taps, mm);
+    if (nt == 64) launch_march_nt<N, NORM, 64>(st, (const void *)in, out, W, H, taps, mm);
+    else launch_march_nt<N, NORM, 128>(st, (const void *)in, out, W, H, taps, mm);
 }
 
 // returns false when no tiled instantiation exists for this tap count
@@ -250,6 +250,37 @@ void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, cons
                    : launch_blur_tiled<false>(p->stream, in, out, W, H, t, p->mm);
     if (!ok) launch_blur_generic(p->stream, in, out, p->tmp, W, H, t, p->mm, norm);
 }
+
+bool taps_symmetric(const Taps &t) {
+    bool symmetric = true;
+    for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
+    return symmetric;
+}
+
+// Initial blur reading a typed (integer / RGB) frame directly: instantiated for the default 15-tap initial
+// kernel (init_sigma = 1.6); any other tap count goes through the convert pass.
+template <int DT>
+bool launch_init_blur_dt(hipStream_t st, const void *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
+    if (t.n != 15) return false;
+    if (W >= 1024 && H >= 512 && taps_symmetric(t) && !getenv("SIFTMI_NO_MARCH"))
+        launch_march_nt<15, true, 128, DT>(st, in, out, W, H, t.t, mm);
+    else
+        launch_blur_t<15, true, DT>(st, in, out, W, H, t.t, mm);
+    return true;
+}
+
+// dispatch F(DT) over the typed-frame codes that have a fused path
+#define SIFTMI_TYPED_DISPATCH(dt, CALL)                       \
+    switch (dt) {                                             \
+        case SIFTMI_U8: { constexpr int DT = 1; CALL; } break;   \
+        case SIFTMI_U16: { constexpr int DT = 2; CALL; } break;  \
+        case SIFTMI_U32: { constexpr int DT = 3; CALL; } break;  \
+        case SIFTMI_U64: { constexpr int DT = 4; CALL; } break;  \
+        case SIFTMI_I32: { constexpr int DT = 5; CALL; } break;  \
+        case SIFTMI_I64: { constexpr int DT = 6; CALL; } break;  \
+        case SIFTMI_RGB8: { constexpr int DT = 8; CALL; } break; \
+        default: break;                                       \
+    }
 
 struct Scope {   // optional hipEvent bracket around one launch (profile=1: blur launches only; 2: every stage)
     siftmi_plan *p; size_t idx = (size_t)-1; hipStream_t st;
@@ -507,7 +538,12 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     if (p->profile) hipEventRecord(p->ev_first, p->stream);
     hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt);
     const float *f32src = (const float *)src;
-    if (image_dtype != SIFTMI_F32) {
+    // Typed frames (u8 / u16 / ... / RGB8) are converted at the point of use by the min/max and the initial blur
+    // (or the plain normalise) -- no f32 copy of the frame in HBM.  Fallback to the convert pass: float64 frames,
+    // a non-default initial tap count, a frame that is not 16-byte aligned.
+    const bool fused_in = image_dtype != SIFTMI_F32 && image_dtype != SIFTMI_F64 && (((uintptr_t)src) & 15) == 0 &&
+                          (!p->have_init || p->taps[5].n == 15) && !getenv("SIFTMI_NO_FUSED_CONVERT");
+    if (image_dtype != SIFTMI_F32 && !fused_in) {
         Scope sc(p, "convert -> float");
         const int g = grid_for((int64_t)N, 256, 4096);
         switch (image_dtype) {
@@ -523,22 +559,37 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         }
         f32src = p->conv;
     }
+    // few, fat workgroups: every block ends with two atomics on the same cache line
+    static const int mm_blocks = getenv("SIFTMI_MM_BLOCKS") ? atoi(getenv("SIFTMI_MM_BLOCKS")) : 256;
     {
         Scope sc(p, "max_min");
         hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, p->stream, p->mm);
-        // few, fat workgroups: every block ends with two atomics on the same cache line
-        static const int mm_blocks = getenv("SIFTMI_MM_BLOCKS") ? atoi(getenv("SIFTMI_MM_BLOCKS")) : 256;
-        hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, mm_blocks)), dim3(256), 0, p->stream, f32src,
-                           (int64_t)N, p->mm);
+        if (fused_in) {
+            SIFTMI_TYPED_DISPATCH(image_dtype, hipLaunchKernelGGL(minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, mm_blocks)),
+                                                                   dim3(256), 0, p->stream, src, (int64_t)N, p->mm));
+        } else {
+            hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, mm_blocks)), dim3(256), 0, p->stream, f32src,
+                               (int64_t)N, p->mm);
+        }
     }
     float *base0 = p->plane(0, 0);
     if (p->have_init) {
         Scope sc(p, "normalize + initial blur", true, (double)N, nullptr, 0);
-        launch_blur(p, f32src, base0, p->W, p->H, p->taps[5], true);
+        if (fused_in) {
+            SIFTMI_TYPED_DISPATCH(image_dtype, launch_init_blur_dt<DT>(p->stream, src, base0, p->W, p->H, p->taps[5], p->mm));
+        } else {
+            launch_blur(p, f32src, base0, p->W, p->H, p->taps[5], true);
+        }
     } else {
         Scope sc(p, "normalize");
-        hipLaunchKernelGGL(normalize_kernel, dim3(grid_for((int64_t)N, 256, 4096)), dim3(256), 0, p->stream, f32src,
-                           base0, (int64_t)N, (const uint32_t *)p->mm);
+        const dim3 g(grid_for((int64_t)N, 256, 4096));
+        if (fused_in) {
+            SIFTMI_TYPED_DISPATCH(image_dtype, hipLaunchKernelGGL(normalize_kernel<DT>, g, dim3(256), 0, p->stream, src, base0, (int64_t)N,
+                                                                   (const uint32_t *)p->mm));
+        } else {
+            hipLaunchKernelGGL(normalize_kernel<0>, g, dim3(256), 0, p->stream, (const void *)f32src, base0, (int64_t)N,
+                               (const uint32_t *)p->mm);
+        }
     }
     char lab[96];
     // Stream `stream` builds the pyramid of every octave back to back; `stream2` runs detection /
@@ -935,7 +986,7 @@ int siftmi_stage_minmax_normalize(int32_t dev, const float *in, float *out, int3
     if ((rc = a.upload(in, N * 4)) || (rc = b.alloc(N * 4)) || (rc = mm.alloc(8))) return rc;
     hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, 0, mm.as<uint32_t>());
     hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, 2048)), dim3(256), 0, 0, a.as<float>(), (int64_t)N, mm.as<uint32_t>());
-    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for((int64_t)N, 256, 4096)), dim3(256), 0, 0, a.as<float>(), b.as<float>(), (int64_t)N, (const uint32_t *)mm.as<uint32_t>());
+    hipLaunchKernelGGL(normalize_kernel<0>, dim3(grid_for((int64_t)N, 256, 4096)), dim3(256), 0, 0, (const void *)a.as<float>(), b.as<float>(), (int64_t)N, (const uint32_t *)mm.as<uint32_t>());
     if ((rc = stage_end())) return rc;
     uint32_t h[2];
     HIPCHK(hipMemcpy(h, mm.p, 8, hipMemcpyDeviceToHost));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-stage device time (hipEvent) of one SiftPlan.keypoints() call: python tools/stage_profile.py [size] [white|smooth] [octaves]"""
+"""Per-stage device time (hipEvent) of one SiftPlan.keypoints() call: python tools/stage_profile.py [size] [white|smooth] [octaves] [dtype]"""
 import os
 import sys
 
@@ -14,8 +14,11 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kind = sys.argv[2] if len(sys.argv) > 2 else "white"
 octaves = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 img = white_noise((size, size)) if kind == "white" else smooth_noise((size, size))
+dtype = sys.argv[4] if len(sys.argv) > 4 else "float32"       # e.g. uint8, uint16 (typed frames)
+if dtype != "float32":
+    img = ((img - img.min()) / (img.max() - img.min()) * np.iinfo(dtype).max).astype(dtype)
 t = torch.from_numpy(img).cuda()
-plan = sp.SiftPlan(shape=img.shape, dtype=np.float32, profile=True, octave_max=octaves or None)
+plan = sp.SiftPlan(shape=img.shape, dtype=img.dtype, profile=True, octave_max=octaves or None)
 for _ in range(3):
     kp = plan.keypoints(t)
 print("image %s %dx%d octaves=%d -> %d keypoints" % (kind, size, size, plan.octave_max, len(kp)))

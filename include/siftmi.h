@@ -128,6 +128,21 @@ int siftmi_match_create(int64_t size, int32_t device_id, int32_t profile, siftmi
 int siftmi_match(siftmi_matcher *plan, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
                  const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th,
                  int32_t *pairs, int64_t capacity, int64_t *n_out, int64_t *n_total);
+/* ROI-masked and mutual-best variants.
+ * siftmi_match_set_roi <- MatchPlan.set_roi / unset_roi (match.py:312-327): uploads the int8 mask (roi = NULL unsets).
+ * siftmi_match_ex      <- the `matching_valid` kernel (matching_cpu.cl:136-199), which the reference compiles but its
+ *                         host code never launches (match.py:246 always calls `matching`).
+ *   roi_mode 0  no mask (== siftmi_match)
+ *   roi_mode 1  `matching_valid` literally: a list-1 keypoint is dropped iff it lies inside the mask array on a zero
+ *               pixel; a list-2 keypoint that is not inside the array on a non-zero pixel keeps competing with
+ *               distance 0 (the kernel guards the accumulation, not the candidate); (c, r) = (int)x, (int)y
+ *   roi_mode 2  strict (extension): keypoints of either list that are not on a non-zero mask pixel do not take part
+ *   mutual      (extension) keep (i, j) only if i is also the nearest list-1 keypoint of j over the same masked
+ *               distances, ties to the smallest index */
+int siftmi_match_set_roi(siftmi_matcher *m, const int8_t *roi, int32_t roi_width, int32_t roi_height);
+int siftmi_match_ex(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
+                    const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th, int32_t roi_mode,
+                    int32_t mutual, int32_t *pairs, int64_t capacity, int64_t *n_out, int64_t *n_total);
 int siftmi_match_last_kernel_ms(const siftmi_matcher *plan, float *ms);
 int siftmi_match_destroy(siftmi_matcher *plan);
 

@@ -213,6 +213,23 @@ def match(kp1, kp2, ratio_th=np.float32(0.73 * 0.73), cap=None):
     return pairs[:min(n, cap)].copy(), int(n)
 
 
+def match_ex(kp1, kp2, roi=None, roi_mode=0, mutual=False, ratio_th=np.float32(0.73 * 0.73), cap=None):
+    """ROI-masked (roi_mode 1: matching_valid literal, 2: strict) and / or mutual-best matching."""
+    kp1 = np.ascontiguousarray(kp1, dtype=dtype_kp); kp2 = np.ascontiguousarray(kp2, dtype=dtype_kp)
+    cap = cap if cap is not None else max(1, kp1.size)
+    pairs = np.full((cap, 2), -1, np.int32)
+    if roi is not None:
+        roi = np.ascontiguousarray(roi, np.int8)
+        rh, rw = roi.shape
+    else:
+        rh = rw = 0
+    lib().so_match_ex.restype = C.c_int64
+    n = lib().so_match_ex(_p(kp1), C.c_int64(kp1.size), _p(kp2), C.c_int64(kp2.size), C.c_float(ratio_th),
+                          _p(roi) if roi is not None else None, C.c_int(rw), C.c_int(rh), C.c_int(roi_mode if roi is not None else 0),
+                          C.c_int(int(mutual)), _p(pairs), C.c_int64(cap))
+    return pairs[:min(n, cap)].copy(), int(n)
+
+
 def octave_count(H, W):
     return lib().so_octave_count(C.c_int(H), C.c_int(W))
 

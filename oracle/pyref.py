@@ -248,6 +248,20 @@ def match(kp1, kp2, ratio=None, cap=None):
     return out[:min(n, cap)].copy(), n
 
 
+def match_valid(kp1, kp2, roi, ratio=None, cap=None):
+    """matching_valid (matching_cpu.cl:136-199) run natively; never launched by the reference's host code."""
+    kp1 = np.ascontiguousarray(kp1, dtype=dtype_kp); kp2 = np.ascontiguousarray(kp2, dtype=dtype_kp)
+    roi = np.ascontiguousarray(roi, np.int8)
+    cap = cap or max(1, kp1.size)
+    ratio = np.float32(PAR["MatchRatio"] * PAR["MatchRatio"]) if ratio is None else np.float32(ratio)
+    out = np.full((cap, 2), -1, np.int32)
+    cnt = np.zeros(1, np.int32)
+    lib().ref_matching_valid(_p(kp1), _p(kp2), _p(roi), C.c_int(roi.shape[1]), C.c_int(roi.shape[0]), _p(out), _p(cnt), C.c_int(cap),
+                             C.c_float(ratio), C.c_int(kp1.size), C.c_int(kp2.size))
+    n = int(cnt[0])
+    return out[:min(n, cap)].copy(), n
+
+
 def transform(image, matrix, offset, out_shape=None, fill=0.0, mode=1):
     """transform / transform_RGB of transform.cl run natively (launch as alignment.py:336-346)."""
     matrix = np.ascontiguousarray(matrix, np.float32).reshape(4); offset = np.ascontiguousarray(offset, np.float32).reshape(2)

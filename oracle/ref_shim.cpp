@@ -79,6 +79,7 @@ void orientation_assignment(void *kps, float *grad, float *ori, int *counter, in
 void descriptor(void *kps, unsigned char *desc, float *grad, float *ori, int octsize, int start,
                 int *end, int W, int H);
 void matching(void *k1, void *k2, void *matchings, int *counter, int max_nb, float ratio, int size1, int size2);
+void matching_valid(void *k1, void *k2, char *valid, int roi_w, int roi_h, void *matchings, int *counter, int max_nb, float ratio, int size1, int size2);
 void transform(float *image, float *output, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode);
 void transform_RGB(unsigned char *image, unsigned char *output, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode);
 }
@@ -168,6 +169,10 @@ void ref_descriptor(void *kps, unsigned char *desc, float *grad, float *ori, int
 }
 void ref_matching(void *k1, void *k2, void *matchings, int *counter, int max_nb, float ratio, int n1, int n2, int nitems) {
     run1d((size_t)nitems, [&] { matching(k1, k2, matchings, counter, max_nb, ratio, n1, n2); });
+}
+
+void ref_matching_valid(void *k1, void *k2, char *valid, int rw, int rh, void *matchings, int *counter, int max_nb, float ratio, int n1, int n2) {
+    run1d((size_t)n1, [&] { matching_valid(k1, k2, valid, rw, rh, matchings, counter, max_nb, ratio, n1, n2); });
 }
 
 void ref_transform(float *image, float *out, void *matrix, void *offset, int W, int H, int OW, int OH, float fill, int mode) {

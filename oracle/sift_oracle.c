@@ -623,6 +623,83 @@ int64_t so_match(const so_record *k1, int64_t n1, const so_record *k2, int64_t n
     return count;
 }
 
+/* ------------------------------------------------------------------ ROI-masked / mutual matching
+ * roi_mode 1 restates `matching_valid` (matching_cpu.cl:136-199) literally, quirks included:
+ *   - a query (list 1) keypoint is dropped only when it lies inside the mask array AND the mask is 0 there
+ *     (keypoints beyond roi_width / roi_height are processed);
+ *   - a list-2 keypoint that fails `inside && mask != 0` is NOT skipped: its distance is 0 (the accumulation
+ *     is what the mask guards), so it competes as a perfect match;
+ *   - (c, r) = (int)x, (int)y.
+ * roi_mode 2 ("strict", an extension): keypoints of either list that are not inside the array on a non-zero
+ * mask pixel do not take part at all.  roi_mode 0: no mask (== so_match).
+ * mutual != 0 (extension): a pair (i, j) is kept only if i is also the nearest list-1 keypoint of j, over the
+ * same masked distances, ties to the smallest index (the reference's strict '<' scan order). */
+static inline int so_roi_inside(const so_record *k, int rw, int rh) {
+    const int c = (int)k->x, r = (int)k->y;
+    return r < rh && c < rw && r >= 0 && c >= 0;
+}
+static inline int so_l1(const uint8_t *a, const uint8_t *b) {
+    int dist = 0;
+    for (int t = 0; t < 128; t++) dist += a[t] > b[t] ? a[t] - b[t] : b[t] - a[t];
+    return dist;
+}
+
+int64_t so_match_ex(const so_record *k1, int64_t n1, const so_record *k2, int64_t n2, float ratio_th,
+                    const int8_t *valid, int rw, int rh, int roi_mode, int mutual, int32_t *pairs, int64_t cap) {
+    if (!valid) roi_mode = 0;
+    int32_t *best = (int32_t *)malloc((size_t)(n1 > 0 ? n1 : 1) * sizeof(int32_t));
+    uint8_t *f1 = (uint8_t *)calloc((size_t)(n1 > 0 ? n1 : 1), 1);   /* 1: query dropped */
+    uint8_t *f2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1);   /* 1: distance forced to 0, 2: excluded */
+    int32_t *rev = (int32_t *)malloc((size_t)(n2 > 0 ? n2 : 1) * sizeof(int32_t));
+    if (!best || !f1 || !f2 || !rev) { free(best); free(f1); free(f2); free(rev); return -1; }
+    for (int64_t i = 0; roi_mode && i < n1; i++) {
+        const int in = so_roi_inside(&k1[i], rw, rh);
+        const int on = in && valid[(size_t)((int)k1[i].y) * rw + (int)k1[i].x] != 0;
+        f1[i] = roi_mode == 1 ? (in && !on) : !on;
+    }
+    for (int64_t j = 0; roi_mode && j < n2; j++) {
+        const int in = so_roi_inside(&k2[j], rw, rh);
+        const int on = in && valid[(size_t)((int)k2[j].y) * rw + (int)k2[j].x] != 0;
+        f2[j] = on ? 0 : (roi_mode == 1 ? 1 : 2);
+    }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n1; i++) {
+        best[i] = -1;
+        if (f1[i]) continue;
+        float d1 = 1000000000000.0f, d2 = 1000000000000.0f;
+        int cur = 0;
+        for (int64_t j = 0; j < n2; j++) {
+            if (f2[j] == 2) continue;
+            const int dist = f2[j] == 1 ? 0 : so_l1(k1[i].desc, k2[j].desc);
+            if ((float)dist < d1) { d2 = d1; d1 = (float)dist; cur = (int)j; }
+            else if ((float)dist < d2) d2 = (float)dist;
+        }
+        best[i] = (d2 != 0.0f && d1 / d2 < ratio_th) ? cur : -1;
+    }
+    if (mutual) {
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t j = 0; j < n2; j++) {
+            rev[j] = -1;
+            if (f2[j] == 2) continue;
+            int dmin = 0x7fffffff;
+            for (int64_t i = 0; i < n1; i++) {
+                if (f1[i]) continue;
+                const int dist = f2[j] == 1 ? 0 : so_l1(k1[i].desc, k2[j].desc);
+                if (dist < dmin) { dmin = dist; rev[j] = (int32_t)i; }
+            }
+        }
+    }
+    int64_t count = 0;
+    for (int64_t i = 0; i < n1; i++) {
+        if (best[i] < 0) continue;
+        if (mutual && rev[best[i]] != (int32_t)i) continue;
+        if (count < cap) { pairs[2 * count] = (int32_t)i; pairs[2 * count + 1] = best[i]; }
+        count++;
+    }
+    free(best); free(f1); free(f2); free(rev);
+    return count;
+}
+
 /* ------------------------------------------------------------------ affine warp  (transform.cl:22-110, 116-204)
  * out[y][x] = bilinear(image, M*(y,x) + off) with the reference's quirks: (y,x) order of the matrix rows
  * ("Fortran convention"), reads guarded by fill at the right/bottom edge, and the final half-pixel cut.

@@ -22,20 +22,29 @@ namespace siftk {
 
 struct MatchPartial { int d1, best, d2, pad; };
 
+// FLAGS (ROI-masked / mutual variants, matching_cpu.cl:136-199): qflag[i] bit 0 = every distance of this query is
+// forced to 0; lflag[j] = 1: distance to this list element is forced to 0 (the literal `matching_valid` behaviour for
+// a masked-out list-2 keypoint), 2: the element does not take part.
+template <bool FLAGS>
 __global__ __launch_bounds__(256) void match_partial_kernel(const uint8_t *__restrict__ kp1, int n1,
                                                             const uint8_t *__restrict__ kp2, int n2, int part_len,
-                                                            MatchPartial *__restrict__ partial) {
+                                                            MatchPartial *__restrict__ partial,
+                                                            const uint8_t *__restrict__ qflag,
+                                                            const uint8_t *__restrict__ lflag) {
     __shared__ uint4 tile[2][SIFT_MATCH_TILE * 8];
+    __shared__ uint8_t tflag[2][SIFT_MATCH_TILE];
     const int tid = threadIdx.x;
     const int j_begin = blockIdx.y * part_len, j_end = min(j_begin + part_len, n2);
     uint32_t q[SIFT_MATCH_QPT][32];
     int qi[SIFT_MATCH_QPT];
     int d1[SIFT_MATCH_QPT], d2[SIFT_MATCH_QPT], best[SIFT_MATCH_QPT];
+    bool qzero[SIFT_MATCH_QPT];
 #pragma unroll
     for (int u = 0; u < SIFT_MATCH_QPT; u++) {
         qi[u] = (blockIdx.x * SIFT_MATCH_QPT + u) * 256 + tid;
         d1[u] = SIFT_MATCH_NONE; d2[u] = SIFT_MATCH_NONE; best[u] = 0;
         const int src = min(qi[u], n1 - 1);
+        qzero[u] = FLAGS && (qflag[src] & 1);
         const uint4 *p = reinterpret_cast<const uint4 *>(kp1 + (size_t)src * 144 + 16);
 #pragma unroll
         for (int w = 0; w < 8; w++) {
@@ -50,16 +59,23 @@ __global__ __launch_bounds__(256) void match_partial_kernel(const uint8_t *__res
         b = reinterpret_cast<const uint4 *>(kp2 + (size_t)jb * 144 + 16)[tid & 7];
     };
     uint4 fa, fb;
-    if (j_begin < j_end) fetch(j_begin, fa, fb);
+    uint8_t ff = 0;
+    if (j_begin < j_end) { fetch(j_begin, fa, fb); if (FLAGS && tid < SIFT_MATCH_TILE) ff = lflag[min(j_begin + tid, n2 - 1)]; }
     int buf = 0;
     for (int j0 = j_begin; j0 < j_end; j0 += SIFT_MATCH_TILE, buf ^= 1) {
         tile[buf][tid] = fa;
         tile[buf][256 + tid] = fb;
+        if (FLAGS && tid < SIFT_MATCH_TILE) tflag[buf][tid] = ff;
         __syncthreads();                      // one barrier per tile: the other buffer is free by construction
-        if (j0 + SIFT_MATCH_TILE < j_end) fetch(j0 + SIFT_MATCH_TILE, fa, fb);
+        if (j0 + SIFT_MATCH_TILE < j_end) {
+            fetch(j0 + SIFT_MATCH_TILE, fa, fb);
+            if (FLAGS && tid < SIFT_MATCH_TILE) ff = lflag[min(j0 + SIFT_MATCH_TILE + tid, n2 - 1)];
+        }
         const int jn = min(SIFT_MATCH_TILE, j_end - j0);
         const uint4 *tb = tile[buf];
         for (int j = 0; j < jn; j++) {
+            int lf = 0;
+            if (FLAGS) { lf = tflag[buf][j]; if (lf == 2) continue; }      // wave-uniform
             uint32_t dist[SIFT_MATCH_QPT];
 #pragma unroll
             for (int u = 0; u < SIFT_MATCH_QPT; u++) dist[u] = 0;
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(256) void match_partial_kernel(const uint8_t *__res
             }
 #pragma unroll
             for (int u = 0; u < SIFT_MATCH_QPT; u++) {
-                const int d = (int)dist[u];
+                const int d = (FLAGS && (lf == 1 || qzero[u])) ? 0 : (int)dist[u];
                 // strict '<' and ascending j: the earliest index wins ties (matching_cpu.cl:92-100)
                 if (d < d1[u]) { d2[u] = d1[u]; d1[u] = d; best[u] = j0 + j; }
                 else if (d < d2[u]) d2[u] = d;
@@ -91,20 +107,27 @@ __global__ __launch_bounds__(256) void match_partial_kernel(const uint8_t *__res
         }
 }
 
-// fold the partitions (ascending) and apply the ratio test (matching_cpu.cl:103-108)
+// fold the partitions (ascending) and apply the ratio test (matching_cpu.cl:103-108).
+// qflag bit 1 (may be null): this query is dropped (`matching_valid`: keypoint on a masked-out pixel).
+// nearest != null: "nearest only" mode for the mutual check -- writes the index of the minimum (-1 if the query was
+// dropped or had no candidate) instead of appending pairs.
 __global__ __launch_bounds__(256) void match_merge_kernel(const MatchPartial *__restrict__ partial, int n1, int nparts,
                                                           float ratio_th, int2 *__restrict__ pairs,
-                                                          int *__restrict__ counter, int capacity) {
+                                                          int *__restrict__ counter, int capacity,
+                                                          const uint8_t *__restrict__ qflag, int *__restrict__ nearest) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n1) return;
+    const bool dropped = qflag && (qflag[i] & 2);
     int d1 = SIFT_MATCH_NONE, d2 = SIFT_MATCH_NONE, best = 0;
-    for (int p = 0; p < nparts; p++) {
+    for (int p = 0; p < nparts && !dropped; p++) {
         const MatchPartial r = partial[(size_t)p * n1 + i];
         // feed the partition's two smallest distances through the reference's update rule, in order
         if (r.d1 < d1) { d2 = d1; d1 = r.d1; best = r.best; }
         else if (r.d1 < d2) d2 = r.d1;
         if (r.d2 < d2) d2 = r.d2;
     }
+    if (nearest) { nearest[i] = (dropped || d1 == SIFT_MATCH_NONE) ? -1 : best; return; }
+    if (dropped) return;
     // distances are stored as float in the reference, initialised to 1e12f
     const float f1 = (d1 == SIFT_MATCH_NONE) ? 1000000000000.0f : (float)d1;
     const float f2 = (d2 == SIFT_MATCH_NONE) ? 1000000000000.0f : (float)d2;
@@ -112,6 +135,42 @@ __global__ __launch_bounds__(256) void match_merge_kernel(const MatchPartial *__
         const int old = atomicAdd(counter, 1);
         if (old < capacity) pairs[old] = make_int2(i, best);
     }
+}
+
+// ROI flags of one keypoint list (matching_cpu.cl:155-158,171-174): (c, r) = (int)x, (int)y;
+// inside = 0 <= r < roi_height && 0 <= c < roi_width;  on = inside && valid[r*roi_width + c] != 0.
+//   as_query: bit 0 = 0, bit 1 = dropped       (mode 1: inside && !on;  mode 2: !on)
+//   as_list : 0 / 1 (distance forced to 0, mode 1 && !on) / 2 (excluded, mode 2 && !on)
+__global__ void match_roi_flags_kernel(const uint8_t *__restrict__ kp, int n, const int8_t *__restrict__ valid,
+                                       int rw, int rh, int mode, uint8_t *__restrict__ as_query, uint8_t *__restrict__ as_list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *k = reinterpret_cast<const float *>(kp + (size_t)i * 144);
+    const int c = (int)k[0], r = (int)k[1];
+    const bool inside = r < rh && c < rw && r >= 0 && c >= 0;
+    const bool on = inside && valid[(size_t)r * rw + c] != 0;
+    as_query[i] = (mode == 1 ? (inside && !on) : !on) ? 2 : 0;
+    as_list[i] = on ? 0 : (mode == 1 ? 1 : 2);
+}
+
+// reverse-direction query flags from the list flags of kp2: list flag 1 -> all distances 0 (bit 0), 2 -> dropped (bit 1)
+__global__ void match_reverse_flags_kernel(const uint8_t *__restrict__ l2, int n2, uint8_t *__restrict__ q2) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n2) q2[j] = l2[j] == 1 ? 1 : (l2[j] == 2 ? 2 : 0);
+}
+// list flags of kp1 for the reverse direction: a dropped query does not take part
+__global__ void match_reverse_list_flags_kernel(const uint8_t *__restrict__ q1, int n1, uint8_t *__restrict__ l1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) l1[i] = (q1[i] & 2) ? 2 : 0;
+}
+
+// mutual check: keep (i, j) iff nearest1_of_2[j] == i; compacts in place order-independently into `out`
+__global__ void match_mutual_filter_kernel(const int2 *__restrict__ pairs, int n, const int *__restrict__ nearest,
+                                           int2 *__restrict__ out, int *__restrict__ counter) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int2 pr = pairs[t];
+    if (nearest[pr.y] == pr.x) out[atomicAdd(counter, 1)] = pr;
 }
 
 }  // namespace siftk

@@ -812,6 +812,16 @@ struct siftmi_matcher {
     int *counter = nullptr;
     hipEvent_t ea = nullptr, eb = nullptr;
     float last_ms = 0;
+    // ROI mask (MatchPlan.set_roi, match.py:312-320) and the scratch of the masked / mutual variants
+    int8_t *roi = nullptr;
+    int64_t cap_roi = 0;
+    int roi_w = 0, roi_h = 0;
+    uint8_t *q1 = nullptr, *l1 = nullptr, *q2 = nullptr, *l2 = nullptr;   // per-keypoint flags (as query / as list element)
+    int64_t cap_q1 = 0, cap_l1 = 0, cap_q2 = 0, cap_l2 = 0;
+    int *nearest = nullptr;
+    int64_t cap_nearest = 0;
+    int2 *pairs2 = nullptr;
+    int64_t cap_pairs2 = 0;
 };
 
 namespace {
@@ -859,6 +869,8 @@ int siftmi_match_destroy(siftmi_matcher *m) {
     if (m->kp2) hipFree(m->kp2);
     if (m->pairs) hipFree(m->pairs);
     if (m->partial) hipFree(m->partial);
+    for (void *q : {(void *)m->roi, (void *)m->q1, (void *)m->l1, (void *)m->q2, (void *)m->l2, (void *)m->nearest, (void *)m->pairs2})
+        if (q) hipFree(q);
     if (m->counter) hipFree(m->counter);
     if (m->ea) hipEventDestroy(m->ea);
     if (m->eb) hipEventDestroy(m->eb);
@@ -867,12 +879,53 @@ int siftmi_match_destroy(siftmi_matcher *m) {
     return SIFTMI_OK;
 }
 
-int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
-                 const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th, int32_t *pairs,
-                 int64_t capacity, int64_t *n_out, int64_t *n_total) {
+int siftmi_match_set_roi(siftmi_matcher *m, const int8_t *roi, int32_t roi_width, int32_t roi_height) {
+    if (!m) return fail(SIFTMI_EINVAL, "null matcher");
+    HIPCHK(hipSetDevice(m->device));
+    if (!roi) { m->roi_w = m->roi_h = 0; return SIFTMI_OK; }       // unset_roi
+    if (roi_width < 1 || roi_height < 1) return fail(SIFTMI_EINVAL, "bad ROI shape %d x %d", roi_width, roi_height);
+    int rc = ensure((void **)&m->roi, &m->cap_roi, (int64_t)roi_width * roi_height, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(m->roi, roi, (size_t)roi_width * roi_height, hipMemcpyHostToDevice));
+    m->roi_w = roi_width; m->roi_h = roi_height;
+    return SIFTMI_OK;
+}
+
+namespace {
+// one direction of the brute-force scan: partials of `nq` queries against `nl` list elements, folded by the merge kernel
+int match_direction(siftmi_matcher *m, const uint8_t *dq, int64_t nq, const uint8_t *dl, int64_t nl, const uint8_t *qflag,
+                    const uint8_t *lflag, float ratio_th, int2 *pairs, int cap, int *nearest) {
+    // 2-D decomposition: query blocks x partitions of the list, enough workgroups to fill 256 CUs
+    const int qblocks = (int)((nq + 256 * SIFT_MATCH_QPT - 1) / (256 * SIFT_MATCH_QPT));
+    int nparts = (2048 + qblocks - 1) / qblocks;
+    const int max_parts = (int)((nl + 4 * SIFT_MATCH_TILE - 1) / (4 * SIFT_MATCH_TILE));
+    if (nparts > max_parts) nparts = max_parts;
+    if (nparts < 1) nparts = 1;
+    int part_len = (int)((nl + nparts - 1) / nparts);
+    part_len = (part_len + SIFT_MATCH_TILE - 1) / SIFT_MATCH_TILE * SIFT_MATCH_TILE;
+    nparts = (int)((nl + part_len - 1) / part_len);
+    int rc;
+    if ((rc = ensure((void **)&m->partial, &m->cap_partial, (int64_t)nparts * nq, sizeof(MatchPartial)))) return rc;
+    const dim3 grid((unsigned)qblocks, (unsigned)nparts);
+    if (lflag)
+        hipLaunchKernelGGL(match_partial_kernel<true>, grid, dim3(256), 0, m->stream, dq, (int)nq, dl, (int)nl, part_len, m->partial, qflag, lflag);
+    else
+        hipLaunchKernelGGL(match_partial_kernel<false>, grid, dim3(256), 0, m->stream, dq, (int)nq, dl, (int)nl, part_len, m->partial,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr);
+    hipLaunchKernelGGL(match_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, m->stream,
+                       (const MatchPartial *)m->partial, (int)nq, nparts, ratio_th, pairs, m->counter, cap, qflag, nearest);
+    return SIFTMI_OK;
+}
+}  // namespace
+
+int siftmi_match_ex(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
+                    const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th, int32_t roi_mode,
+                    int32_t mutual, int32_t *pairs, int64_t capacity, int64_t *n_out, int64_t *n_total) {
     if (!m || !n_out) return fail(SIFTMI_EINVAL, "null argument");
     if (n1 < 0 || n2 < 0 || n1 > 0x7fffffff || n2 > 0x7fffffff) return fail(SIFTMI_EINVAL, "bad list size");
     if ((n1 > 0 && !kp1) || (n2 > 0 && !kp2)) return fail(SIFTMI_EINVAL, "null keypoint list");
+    if (roi_mode < 0 || roi_mode > 2) return fail(SIFTMI_EINVAL, "roi_mode must be 0 (off), 1 (matching_valid) or 2 (strict)");
+    if (roi_mode && !(m->roi && m->roi_w > 0)) return fail(SIFTMI_EINVAL, "roi_mode %d without a region of interest (siftmi_match_set_roi)", roi_mode);
     HIPCHK(hipSetDevice(m->device));
     *n_out = 0;
     if (n_total) *n_total = 0;
@@ -894,25 +947,43 @@ int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int3
     int64_t cap = m->size;
     if ((n1 < n2 ? n1 : n2) > cap) cap = (n1 < n2 ? n1 : n2);
     if ((rc = ensure((void **)&m->pairs, &m->cap_pairs, cap, sizeof(int2)))) return rc;
-    HIPCHK(hipMemsetAsync(m->counter, 0, 4, m->stream));
-    // 2-D decomposition: query blocks x partitions of the second list, enough workgroups to fill 256 CUs
-    const int qblocks = (int)((n1 + 256 * SIFT_MATCH_QPT - 1) / (256 * SIFT_MATCH_QPT));
-    int nparts = (2048 + qblocks - 1) / qblocks;
-    const int max_parts = (int)((n2 + 4 * SIFT_MATCH_TILE - 1) / (4 * SIFT_MATCH_TILE));
-    if (nparts > max_parts) nparts = max_parts;
-    if (nparts < 1) nparts = 1;
-    int part_len = (int)((n2 + nparts - 1) / nparts);
-    part_len = (part_len + SIFT_MATCH_TILE - 1) / SIFT_MATCH_TILE * SIFT_MATCH_TILE;
-    nparts = (int)((n2 + part_len - 1) / part_len);
-    if ((rc = ensure((void **)&m->partial, &m->cap_partial, (int64_t)nparts * n1, sizeof(MatchPartial)))) return rc;
+    HIPCHK(hipMemsetAsync(m->counter, 0, 8, m->stream));
     hipEventRecord(m->ea, m->stream);
-    hipLaunchKernelGGL(match_partial_kernel, dim3((unsigned)qblocks, (unsigned)nparts), dim3(256), 0, m->stream, d1, (int)n1,
-                       d2, (int)n2, part_len, m->partial);
-    hipLaunchKernelGGL(match_merge_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, m->stream,
-                       (const MatchPartial *)m->partial, (int)n1, nparts, ratio_th, m->pairs, m->counter, (int)cap);
-    hipEventRecord(m->eb, m->stream);
+    const uint8_t *qf1 = nullptr, *lf2 = nullptr;
+    if (roi_mode) {
+        if ((rc = ensure((void **)&m->q1, &m->cap_q1, n1, 1)) || (rc = ensure((void **)&m->l1, &m->cap_l1, n1, 1)) ||
+            (rc = ensure((void **)&m->q2, &m->cap_q2, n2, 1)) || (rc = ensure((void **)&m->l2, &m->cap_l2, n2, 1))) return rc;
+        hipLaunchKernelGGL(match_roi_flags_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, m->stream, d1, (int)n1,
+                           (const int8_t *)m->roi, m->roi_w, m->roi_h, roi_mode, m->q1, m->l1);
+        hipLaunchKernelGGL(match_roi_flags_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, m->stream, d2, (int)n2,
+                           (const int8_t *)m->roi, m->roi_w, m->roi_h, roi_mode, m->q2, m->l2);
+        qf1 = m->q1; lf2 = m->l2;
+    }
+    if ((rc = match_direction(m, d1, n1, d2, n2, qf1, lf2, ratio_th, m->pairs, (int)cap, nullptr))) return rc;
+    int2 *result = m->pairs;
+    int *result_counter = m->counter;
     int count = 0;
-    HIPCHK(hipMemcpyAsync(&count, m->counter, 4, hipMemcpyDeviceToHost, m->stream));
+    if (mutual) {
+        // reverse scan: nearest list-1 keypoint of every list-2 keypoint over the same masked distances
+        if ((rc = ensure((void **)&m->nearest, &m->cap_nearest, n2, sizeof(int))) ||
+            (rc = ensure((void **)&m->pairs2, &m->cap_pairs2, cap, sizeof(int2)))) return rc;
+        const uint8_t *qf2 = nullptr, *lf1 = nullptr;
+        if (roi_mode) {
+            hipLaunchKernelGGL(match_reverse_flags_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, m->stream, (const uint8_t *)m->l2, (int)n2, m->q2);
+            hipLaunchKernelGGL(match_reverse_list_flags_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, m->stream, (const uint8_t *)m->q1, (int)n1, m->l1);
+            qf2 = m->q2; lf1 = m->l1;
+        }
+        HIPCHK(hipMemcpyAsync(&count, m->counter, 4, hipMemcpyDeviceToHost, m->stream));   // forward count (the partial buffer is reused below)
+        if ((rc = match_direction(m, d2, n2, d1, n1, qf2, lf1, ratio_th, nullptr, 0, m->nearest))) return rc;
+        HIPCHK(hipStreamSynchronize(m->stream));
+        const int nfwd = count < cap ? count : (int)cap;
+        if (nfwd > 0)
+            hipLaunchKernelGGL(match_mutual_filter_kernel, dim3((unsigned)((nfwd + 255) / 256)), dim3(256), 0, m->stream,
+                               (const int2 *)m->pairs, nfwd, (const int *)m->nearest, m->pairs2, m->counter + 1);
+        result = m->pairs2; result_counter = m->counter + 1;
+    }
+    hipEventRecord(m->eb, m->stream);
+    HIPCHK(hipMemcpyAsync(&count, result_counter, 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     HIPCHK(hipGetLastError());
     hipEventElapsedTime(&m->last_ms, m->ea, m->eb);
@@ -922,10 +993,16 @@ int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int3
     if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "pair capacity too small; result truncated"; }
     if (n > 0) {
         if (!pairs) return fail(SIFTMI_EINVAL, "null pairs buffer");
-        HIPCHK(hipMemcpy(pairs, m->pairs, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pairs, result, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
     }
     *n_out = n;
     return rc;
+}
+
+int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int32_t kp1_is_device,
+                 const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th, int32_t *pairs,
+                 int64_t capacity, int64_t *n_out, int64_t *n_total) {
+    return siftmi_match_ex(m, kp1, n1, kp1_is_device, kp2, n2, kp2_is_device, ratio_th, 0, 0, pairs, capacity, n_out, n_total);
 }
 
 int siftmi_match_last_kernel_ms(const siftmi_matcher *m, float *ms) {

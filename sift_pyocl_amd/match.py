@@ -68,11 +68,17 @@ class MatchPlan(object):
                 pass
             self._handle = None
 
-    def match(self, nkp1, nkp2, raw_results=False):
+    ROI_MODES = {0: 0, None: 0, False: 0, "off": 0, 1: 1, True: 1, "reference": 1, "matching_valid": 1, 2: 2, "strict": 2}
+
+    def match(self, nkp1, nkp2, raw_results=False, roi_mode=0, mutual=False):
         """Calculate the matching of 2 keypoint lists
 
         :param nkp1, nkp2: numpy 1D recarray of keypoints (or device tensors of 144-byte records)
         :param raw_results: if true return the 2D array of indexes of matching keypoints (not the actual keypoints)
+        :param roi_mode: 0 (default) ignores the region of interest, exactly like the reference, whose ``match`` never
+                         reaches its ``matching_valid`` kernel; "reference" / 1 runs that kernel's semantics literally
+                         (matching_cpu.cl:136-199); "strict" / 2 drops every keypoint that is not on a non-zero pixel
+        :param mutual: keep only pairs that are nearest neighbours in both directions (extension)
         """
         assert len(nkp1.shape) == 1
         assert len(nkp2.shape) == 1
@@ -87,8 +93,11 @@ class MatchPlan(object):
             n = C.c_int64(0)
             total = C.c_int64(0)
             ratio = numpy.float32(par.MatchRatio * par.MatchRatio)
-            _lib.check(L.siftmi_match(self._handle, p1, n1, dev1, p2, n2, dev2, C.c_float(ratio), pairs.ctypes.data,
-                                      cap, C.byref(n), C.byref(total)), allow=(_lib.ECAPACITY,))
+            mode = self.ROI_MODES[roi_mode]
+            if mode and self.roi is None:
+                raise RuntimeError("roi_mode=%r needs a region of interest (set_roi)" % (roi_mode,))
+            _lib.check(L.siftmi_match_ex(self._handle, p1, n1, dev1, p2, n2, dev2, C.c_float(ratio), mode, int(bool(mutual)),
+                                         pairs.ctypes.data, cap, C.byref(n), C.byref(total)), allow=(_lib.ECAPACITY,))
             size = int(n.value)
             match = pairs[:size].copy()
             if raw_results:
@@ -125,10 +134,16 @@ class MatchPlan(object):
             self.events = []
 
     def set_roi(self, roi):
-        """Stored but unused, exactly as in the reference (match.py:312-327 never reaches the kernel)."""
+        """Defines the region of interest (match.py:312-320): 2D array, non zero where pixels are valid.  As in the
+        reference it has no effect on ``match()`` unless ``roi_mode`` is given."""
         with self._sem:
             self.roi = numpy.ascontiguousarray(roi, numpy.int8)
+            if self.roi.ndim != 2:
+                raise RuntimeError("the region of interest must be a 2D array")
+            _lib.check(_lib.lib().siftmi_match_set_roi(self._handle, self.roi.ctypes.data, self.roi.shape[1], self.roi.shape[0]))
 
     def unset_roi(self):
+        """Unset the region of interest (match.py:322-327)"""
         with self._sem:
             self.roi = None
+            _lib.check(_lib.lib().siftmi_match_set_roi(self._handle, None, 0, 0))

@@ -50,3 +50,31 @@ def test_transform_identical(oracle, ref):
             assert np.array_equal(oracle.transform(rgb, M, off, fill=fill, mode=mode), ref.transform(rgb, M, off, fill=fill, mode=mode))
         a = oracle.transform(img, M, off, out_shape=(180, 230), fill=fill); b = ref.transform(img, M, off, out_shape=(180, 230), fill=fill)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_matching_valid_identical(oracle, ref):
+    """so_match_ex(roi_mode=1) against the reference's `matching_valid` kernel (never launched by its host code)."""
+    from util import dtype_kp
+    rng = np.random.default_rng(5)
+    n1, n2, H, W = 600, 550, 90, 120
+    a = np.zeros(n1, dtype_kp); b = np.zeros(n2, dtype_kp)
+    a["desc"] = rng.integers(0, 256, (n1, 128), dtype=np.uint8); b["desc"] = rng.integers(0, 256, (n2, 128), dtype=np.uint8)
+    idx = rng.permutation(n1)[:300]
+    b["desc"][:300] = np.clip(a["desc"][idx].astype(int) + rng.integers(-6, 7, (300, 128)), 0, 255).astype(np.uint8)
+    roi = (rng.random((H, W)) > 0.3).astype(np.int8)
+    ys, xs = np.nonzero(roi)
+    pick = rng.integers(0, len(ys), n2)
+    b["x"] = xs[pick] + 0.4; b["y"] = ys[pick] + 0.6                  # list 2 entirely on valid pixels
+    a["x"] = rng.random(n1) * W * 1.2; a["y"] = rng.random(n1) * H * 1.2   # list 1 anywhere, also beyond the array
+    p_o, n_o = oracle.match_ex(a, b, roi, 1); p_r, n_r = ref.match_valid(a, b, roi)
+    assert n_o == n_r and 0 < n_o < 300 and np.array_equal(sort_rows(p_o), sort_rows(p_r))
+    # one masked-out list-2 keypoint wins everything; two of them suppress every pair
+    zy, zx = np.argwhere(roi == 0)[0]
+    b["x"][7] = zx + 0.5; b["y"][7] = zy + 0.5
+    p_o, n_o = oracle.match_ex(a, b, roi, 1); p_r, n_r = ref.match_valid(a, b, roi)
+    assert n_o == n_r and n_o > 300 and np.array_equal(sort_rows(p_o), sort_rows(p_r)) and (p_o[:, 1] == 7).all()
+    b["x"][8] = zx + 0.5; b["y"][8] = zy + 0.5
+    assert oracle.match_ex(a, b, roi, 1)[1] == 0 == ref.match_valid(a, b, roi)[1]
+    # list-2 keypoints beyond the array also count as masked out
+    b["x"][8] = W + 3.0
+    assert oracle.match_ex(a, b, roi, 1)[1] == 0 == ref.match_valid(a, b, roi)[1]

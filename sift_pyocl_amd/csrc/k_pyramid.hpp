@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ i
 //     (N+1)/2 distinct products per row are formed; each is the same IEEE product the reference
 //     computes.  With the march unrolled N times every accumulator index is a compile-time constant.
 // No FMA anywhere: the pyramid is bit-identical to the reference's unfused arithmetic.
+// dev-only ablation switches for tools/ubench/blur_abl.hip (0 in every product build)
+#ifndef BLUR_ABL
+#define BLUR_ABL 0
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -389,6 +393,13 @@ __global__ __launch_bounds__(NT) void blur_march_kernel(const void *__restrict__
     f32x2 pa[G::NP], pb[G::NP], ph[G::NB];
     auto prefetch = [&](int blk) {
         const int v0 = ys - G::C + blk * N;
+        if (BLUR_ABL & 4) {
+#pragma unroll
+            for (int rp = 0; rp < G::NP; rp++) { pa[rp] = (f32x2){1.f, 2.f}; pb[rp] = (f32x2){3.f, 4.f}; }
+#pragma unroll
+            for (int u = 0; u < G::NB; u++) ph[u] = (f32x2){5.f, 6.f};
+            return;
+        }
         if (v0 >= 0 && v0 + N + 1 <= H) {             // interior rows: walk per-thread offsets
             unsigned oa = ((unsigned)v0 * (unsigned)W + (unsigned)gx_a) * 4u;
             unsigned ob = ((unsigned)v0 * (unsigned)W + (unsigned)gx_b) * 4u;
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(NT) void blur_march_kernel(const void *__restrict__
         if (blk + 1 < nblocks) prefetch(blk + 1);
         // ---- horizontal pass in place: a task = 4 consecutive columns of one row pair; the NT/2 tasks of a
         //      row pair are consecutive lanes of one wave (a whole wave for NT = 128, half a wave for NT = 64)
-        for (int task = tid; task < G::NP * (NT / 2); task += NT) {
+        for (int task = tid; task < ((BLUR_ABL & 1) ? 0 : G::NP * (NT / 2)); task += NT) {
             const int rp = task / (NT / 2), t4 = task % (NT / 2);
             float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
             // sliding window streamed through registers: b128 loads run PRE ahead of their first use
@@ -481,22 +492,28 @@ __global__ __launch_bounds__(NT) void blur_march_kernel(const void *__restrict__
                 const int kk = 2 * rp + half;
                 if (kk < N) {
                     const f32x2 h = half ? hv.zw : hv.xy;
-                    f32x2 prod[(N + 1) / 2];
+                    // taps[N-1-j] == taps[j] bitwise: product k feeds the two outputs whose tap index is k or N-1-k.
+                    // Each accumulator receives exactly one addition per input row, so the order of the additions
+                    // within a row is free; forming a product and retiring it at once keeps one product live, not (N+1)/2.
 #pragma unroll
-                    for (int k = 0; k < (N + 1) / 2; k++) { const f32x2 t2 = {taps.t[k], taps.t[k]}; prod[k] = h * t2; }
-#pragma unroll
-                    for (int j = 0; j < N; j++) {
-                        const int slot = (kk - j + N) % N;
-                        const int k = (j < N - 1 - j) ? j : N - 1 - j;   // taps[N-1-j] == taps[j] bitwise
-                        if (j == 0) acc[slot] = (f32x2){0.f, 0.f} + prod[k];
-                        else acc[slot] = acc[slot] + prod[k];
-                        // Pin the addition here: otherwise the compiler sinks each output's whole
+                    for (int k = 0; k < ((BLUR_ABL & 2) ? 1 : (N + 1) / 2); k++) {
+                        const f32x2 t2 = {taps.t[k], taps.t[k]};
+                        const f32x2 prod = h * t2;
+                        const int slot_a = (kk - k + N) % N;             // tap index j = k
+                        const int slot_b = (kk - (N - 1 - k) + N) % N;   // tap index j = N-1-k
+                        if (k == 0) acc[slot_a] = (f32x2){0.f, 0.f} + prod;
+                        else acc[slot_a] = acc[slot_a] + prod;
+                        // Pin the additions here: otherwise the compiler sinks each output's whole
                         // add chain into its (conditional) store and keeps every product alive.
-                        asm volatile("" : "+v"(acc[slot]));
+                        asm volatile("" : "+v"(acc[slot_a]));
+                        if (k != N - 1 - k) {
+                            acc[slot_b] = acc[slot_b] + prod;
+                            asm volatile("" : "+v"(acc[slot_b]));
+                        }
                     }
                     const int done = (kk + 1) % N;    // the output whose last tap (j = N-1) was just added
                     const int y = ybase + kk;
-                    if (y >= ys && y < yend) {
+                    if (y >= ys && y < yend && !((BLUR_ABL & 8) && acc[done].x != 12345.678f)) {
                         if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];
                         else {
                             if (gxo < W) optr[0] = acc[done].x;

@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--size", type=int, default=SIZE, help="image side (default: the BASELINE config, 4096)")
     ap.add_argument("--octaves", type=int, default=OCTAVES, help="0 = every octave (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 "
+                                                      "code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -88,11 +91,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
+    # collectives run on device tensors with RCCL; the gloo rehearsal stages them through the host
+    xdev = "cuda" if args.backend == "nccl" else "cpu"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     import sift_pyocl_amd as sp
     from sift_pyocl_amd.batch import RECORD_BYTES
@@ -115,8 +125,8 @@ def main():
     for i in range(W):
         last = plan.keypoints(dev_images[i % n_img])
     if distributed:   # warm the collective path too
-        t = torch.zeros(8, dtype=torch.uint8, device="cuda")
-        o = torch.empty(8 * world, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(8, dtype=torch.uint8, device=xdev)
+        o = torch.empty(8 * world, dtype=torch.uint8, device=xdev)
         dist.all_gather_into_tensor(o, t)
 
     blur_ms = blur_px = tot_ms = 0.0
@@ -135,22 +145,22 @@ def main():
         b0_ms += kt["blur0_ms"]; b0_px += kt["blur0_pixels"]; b0_launches += kt["blur0_launches"]
     if distributed:
         # the batched path's single exchange step: all-gather of the keypoint records (padded)
-        cnt = torch.tensor([len(last)], dtype=torch.int64, device="cuda")
-        cnts = torch.empty(world, dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([len(last)], dtype=torch.int64, device=xdev)
+        cnts = torch.empty(world, dtype=torch.int64, device=xdev)
         dist.all_gather_into_tensor(cnts, cnt)
         mx = int(cnts.max().item())
-        buf = torch.zeros(max(1, mx) * RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        buf = torch.zeros(max(1, mx) * RECORD_BYTES, dtype=torch.uint8, device=xdev)
         raw = torch.from_numpy(np.ascontiguousarray(last).view(np.uint8).reshape(-1).copy())
-        buf[:raw.numel()] = raw.cuda()
-        allbuf = torch.empty(world * buf.numel(), dtype=torch.uint8, device="cuda")
+        buf[:raw.numel()] = raw.to(xdev)
+        allbuf = torch.empty(world * buf.numel(), dtype=torch.uint8, device=xdev)
         dist.all_gather_into_tensor(allbuf, buf)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-        tk = torch.tensor([float(n_kp)], dtype=torch.float64, device="cuda")
+        tk = torch.tensor([float(n_kp)], dtype=torch.float64, device=xdev)
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         total_kp = float(tk.item())
     else:

@@ -117,6 +117,24 @@ int siftmi_plan_blur_ms(const siftmi_plan *plan, int32_t octave, float *blur_ms,
                         double *blur_pixels);
 int siftmi_plan_destroy(siftmi_plan *plan);
 
+/* ---- batched, pipelined keypoints -----------------------------------------------------------
+ * The reference processes one image per SiftPlan.keypoints call and blocks on >= 18 counter read-backs per octave
+ * (plan.py:642,689,731,767,777); a stack of frames is a Python loop (scripts/sift_pyocl.py, LinearAlign).  The batch
+ * handle is the throughput form of that loop: `lanes` independent plans take the images round-robin,
+ * nothing waits until a lane is reused, the records of the whole batch are parked on the device and handed back by one copy.
+ *   siftmi_batch_keypoints  images[n]: all host or all device pointers of the batch's shape / dtype (or float32);
+ *                           counts[n], offsets[n] (in records, into the parked result) and *total are returned
+ *   siftmi_batch_fetch      copies records [first, first+count) of the parked result (host or device destination) */
+typedef struct siftmi_batch siftmi_batch;
+int siftmi_batch_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id, const siftmi_params *params,
+                        int32_t lanes, siftmi_batch **out);
+int siftmi_batch_destroy(siftmi_batch *batch);
+int siftmi_batch_set_params(siftmi_batch *batch, const siftmi_params *params);
+int siftmi_batch_info(const siftmi_batch *batch, int32_t *lanes, int64_t *bytes_allocated);
+int siftmi_batch_keypoints(siftmi_batch *batch, const void *const *images, int32_t n_images, int32_t image_dtype,
+                           int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow);
+int siftmi_batch_fetch(siftmi_batch *batch, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count);
+
 /* ---- MatchPlan -----------------------------------------------------------------------------
  * siftmi_match_create <- MatchPlan.__init__ (match.py:77-139)
  * siftmi_match        <- MatchPlan.match (match.py:200-271) with the `matching` kernel

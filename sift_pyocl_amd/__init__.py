@@ -9,5 +9,6 @@ from .param import par
 from .plan import SiftPlan
 from .match import MatchPlan
 from .alignment import LinearAlign
+from .batch import BatchPlan
 
-__all__ = ["par", "SiftPlan", "MatchPlan", "LinearAlign", "version"]
+__all__ = ["par", "SiftPlan", "MatchPlan", "LinearAlign", "BatchPlan", "version"]

@@ -55,6 +55,13 @@ _SIGNATURES = {
     "siftmi_match_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "siftmi_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                C.c_float, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "siftmi_batch_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "siftmi_batch_destroy": (C.c_int, [C.c_void_p]),
+    "siftmi_batch_set_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "siftmi_batch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "siftmi_batch_keypoints": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "siftmi_batch_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),
     "siftmi_match_set_roi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "siftmi_match_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -6,11 +6,114 @@ The reference has no multi-device code at all (one pyopencl.Context per plan, si
 a user would build one plan per device.  Images are independent, so the data path needs no
 collective; only the result hand-back is a collective, and it is small (144 B per keypoint).
 """
+import ctypes as C
+import logging
+
 import numpy
 
-from .plan import SiftPlan
+from . import _lib
+from .param import par
+from .plan import SiftPlan, _pointer_of
 
+logger = logging.getLogger("sift.batch")
 RECORD_BYTES = 144
+
+
+class BatchPlan(SiftPlan):
+    """Throughput form of ``SiftPlan`` for stacks of same-shape frames.
+
+    ``lanes`` independent device plans take the frames round-robin; nothing waits on the host until a lane is
+    reused, the records of the whole batch are parked on the device and come back in one copy
+    (``siftmi_batch_*`` in include/siftmi.h).  Same constructor keywords as ``SiftPlan`` plus ``lanes``;
+    ``keypoints_batch(images)`` returns one recarray per frame, each bit-identical to ``SiftPlan.keypoints``.
+    """
+
+    def __init__(self, *args, **kwargs):
+        self.lanes = int(kwargs.pop("lanes", 4))
+        if kwargs.get("profile"):
+            raise RuntimeError("BatchPlan does not collect per-stage events; profile a SiftPlan instead")
+        SiftPlan.__init__(self, *args, **kwargs)
+
+    def _create(self, L):
+        _lib.check(L.siftmi_batch_create(self.shape[0], self.shape[1], self._code, self.device, C.byref(self._params),
+                                         self.lanes, C.byref(self._handle)))
+        nbytes = C.c_int64()
+        _lib.check(L.siftmi_batch_info(self._handle, None, C.byref(nbytes)))
+        self.memory = int(nbytes.value)
+
+    def _destroy(self, L, h):
+        L.siftmi_batch_destroy(h)
+
+    def keypoints_batch(self, images):
+        """Keypoints of a sequence of frames (all numpy / host, or all device tensors).
+
+        :return: list of numpy recarrays (x, y, scale, angle, desc[128]), one per frame, in input order
+        """
+        images = list(images)
+        n = len(images)
+        if n == 0:
+            return []
+        with self._sem:
+            L = _lib.lib()
+            key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
+            if key != self._par_key:
+                params = self._current_params()
+                _lib.check(L.siftmi_batch_set_params(self._handle, C.byref(params)))
+                self._params, self._par_key = params, key
+            ptrs = (C.c_void_p * n)()
+            keep = []
+            dev_flags = set()
+            code = None
+            for i, image in enumerate(images):
+                ptr, is_dev, dtype, shape, k = _pointer_of(image)
+                assert tuple(shape[:2]) == tuple(self.shape)
+                assert dtype in [self.dtype, numpy.float32]
+                if dtype == numpy.float32 and len(shape) == 2:
+                    c = _lib.DTYPE_CODES["float32"]
+                elif self.dtype == numpy.float64 and dtype == numpy.float64:
+                    k = k.float() if is_dev else k.astype(numpy.float32)
+                    ptr = k.data_ptr() if is_dev else k.ctypes.data
+                    c = _lib.DTYPE_CODES["float32"]
+                elif len(shape) == 3 and dtype == numpy.uint8 and self.RGB:
+                    c = _lib.DTYPE_CODES["rgb8"]
+                elif self.dtype in self.converter and len(shape) == 2:
+                    c = _lib.DTYPE_CODES[self.dtype.name]
+                else:
+                    raise RuntimeError("invalid input format error (%s)" % (str(self.dtype)))
+                if code is None:
+                    code = c
+                elif c != code:
+                    raise RuntimeError("all frames of a batch must have the same element type")
+                ptrs[i] = ptr
+                keep.append(k)
+                dev_flags.add(int(bool(is_dev)))
+            if len(dev_flags) != 1:
+                raise RuntimeError("the frames of a batch must be all host arrays or all device tensors")
+            counts = (C.c_int64 * n)()
+            offsets = (C.c_int64 * n)()
+            total = C.c_int64(0)
+            ovf = C.c_int32(0)
+            _lib.check(L.siftmi_batch_keypoints(self._handle, ptrs, n, code, dev_flags.pop(), counts, offsets, C.byref(total),
+                                                C.byref(ovf)))
+            self.overflow = bool(ovf.value)
+            if self.overflow:
+                logger.warning("Keypoint counter overflow: more than %s keypoints in a frame, result truncated", self.kpsize)
+            flat = numpy.empty(total.value, dtype=self.dtype_kp)
+            if total.value:
+                _lib.check(L.siftmi_batch_fetch(self._handle, flat.ctypes.data, 0, 0, total.value))
+            del keep
+        return [flat[offsets[i]:offsets[i] + counts[i]].view(numpy.recarray) for i in range(n)]
+
+    def keypoints(self, image):
+        return self.keypoints_batch([image])[0]
+
+    __call__ = keypoints
+
+    def minmax(self):
+        raise RuntimeError("BatchPlan keeps no per-frame min/max; use SiftPlan")
+
+    def kernel_times(self):
+        raise RuntimeError("BatchPlan does not collect per-stage events; profile a SiftPlan instead")
 
 
 def shard_indices(n_items, rank, world_size):
@@ -65,8 +168,9 @@ def gather_records(local_records, n_items, rank, world_size, device=None, group=
 def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, device=None, **plan_kwargs):
     """Keypoints of a list of same-shape images, sharded over the ranks of the default process group.
 
-    Without an initialised process group this degenerates to a plain loop on one GPU.
-    Every rank must pass the same `images` list (only the owned ones are touched).
+    Each rank runs its share through a ``BatchPlan`` (pipelined, one result copy); without an initialised process
+    group everything runs on one GPU.  Every rank must pass the same `images` list (only the owned ones are touched).
+    A ``SiftPlan`` passed as `plan` is used frame by frame.
     """
     import torch.distributed as dist
 
@@ -77,8 +181,11 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
             rank, world_size = 0, 1
     mine = shard_indices(len(images), rank, world_size)
     if plan is None and mine:
-        plan = SiftPlan(template=images[mine[0]], **plan_kwargs)
-    local = [plan.keypoints(images[i]) for i in mine]
+        plan = BatchPlan(template=images[mine[0]], **plan_kwargs)
+    if isinstance(plan, BatchPlan):
+        local = plan.keypoints_batch([images[i] for i in mine])
+    else:
+        local = [plan.keypoints(images[i]) for i in mine]
     if not gather or world_size == 1:
         if world_size == 1:
             return local

@@ -116,6 +116,9 @@ struct siftmi_plan {
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
     void *raw = nullptr;          // host-input staging (any dtype)
     int raw_dtype = -1;           // dtype of the image currently staged in `raw` (-1: none)
+    hipStream_t fin = nullptr;    // stream on which the last enqueued image ends
+    hipEvent_t ev_join = nullptr;
+    struct HostBack { Counters c; uint32_t mm[2]; } *hb = nullptr;   // pinned read-back block (one async D->H + one wait per image)
     void *warp_in = nullptr, *warp_out = nullptr;   // siftmi_plan_transform staging, grown on demand
     size_t warp_in_bytes = 0, warp_out_bytes = 0;
     hipEvent_t ev_wa = nullptr, ev_wb = nullptr;
@@ -479,6 +482,8 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
+    if (p->hb) hipHostFree(p->hb);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
     if (p->warp_in) hipFree(p->warp_in);
     if (p->warp_out) hipFree(p->warp_out);
     if (p->ev_wa) hipEventDestroy(p->ev_wa);
@@ -510,19 +515,23 @@ int siftmi_plan_set_params(siftmi_plan *p, const siftmi_params *params) {
     return resched ? compute_schedule(p) : SIFTMI_OK;
 }
 
-int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t image_is_device, siftmi_keypoint *out,
-                          int32_t out_is_device, int64_t capacity, int64_t *n_out, int32_t *overflow) {
-    if (!p || !image || !n_out) return fail(SIFTMI_EINVAL, "null argument");
-    if (capacity > 0 && !out) return fail(SIFTMI_EINVAL, "null output with capacity > 0");
+}  // extern "C"
+
+namespace {
+int enqueue_body(siftmi_plan *p);
+
+// Enqueue the whole pipeline of one image on the plan's streams, ending with the asynchronous read-back of the
+// counters into the plan's pinned block.  No host wait.  `sync_device`: order after the caller's other streams.
+int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t image_is_device, bool sync_device) {
     if (image_dtype != p->dtype && image_dtype != SIFTMI_F32)
         return fail(SIFTMI_EINVAL, "image dtype %d is neither the plan's (%d) nor float32", image_dtype, p->dtype);
     HIPCHK(hipSetDevice(p->device));
-    *n_out = 0;
-    if (overflow) *overflow = 0;
+    if (!p->hb) HIPCHK(hipHostMalloc((void **)&p->hb, sizeof(*p->hb), hipHostMallocDefault));
+    if (!p->ev_join) HIPCHK(hipEventCreate(&p->ev_join));
     const size_t N = (size_t)p->H * p->W;
     const void *src = image;
     if (image_is_device) {
-        HIPCHK(hipDeviceSynchronize());   // order after the caller's work on other streams
+        if (sync_device) HIPCHK(hipDeviceSynchronize());   // order after the caller's work on other streams
     } else {
         HIPCHK(hipMemcpyAsync(p->raw, image, N * dtype_size(image_dtype), hipMemcpyHostToDevice, p->stream));
         src = p->raw;
@@ -591,6 +600,16 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
                                (const uint32_t *)p->mm);
         }
     }
+    // ---- everything below depends on plan-owned buffers only
+    int rc;
+    rc = enqueue_body(p);
+    if (htime) fprintf(stderr, "[siftmi] enqueue %.0f us\n", tnow() - t_enter);
+    return rc;
+}
+
+// Pyramid of every octave, detection, orientation, description, read-back of the counters: the part of one image's
+// work that touches plan-owned buffers only (so it can be captured once and replayed).  Sets p->fin.
+int enqueue_body(siftmi_plan *p) {
     char lab[96];
     // Stream `stream` builds the pyramid of every octave back to back; `stream2` runs detection /
     // description of octave o as soon as its six planes exist, overlapping the (small, latency-bound)
@@ -631,23 +650,42 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         if (oct == 0) launch_describe_group(p, 0, dst);
         else if (oct == p->n_oct - 1) {
             launch_describe_group(p, 1, dst);
-            if (p->overlap) {
-                HIPCHK(hipEventRecord(p->ev_grp1, dst));
-                HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_grp1, 0));   // stream2 ends last
-            }
+            if (p->overlap) HIPCHK(hipEventRecord(p->ev_grp1, dst));
         }
     }
-    hipStream_t fin = (p->overlap && p->n_oct > 0) ? p->stream2 : p->stream;
+    // Both detection streams rejoin the pyramid stream, which ends the image with the read-back of the counters.
+    // (Capturing this fork / join into a hipGraph was tried: it replays correctly -- as long as stream3 does not rejoin
+    // through stream2, which crashes hipStreamEndCapture on ROCm 7.2 -- but a graph launch is no faster than the ~35 plain
+    // launches: small images are bound by the GPU-side latency of dependent kernels, not by host launch cost.)
+    if (p->overlap && p->n_oct > 0) {
+        HIPCHK(hipEventRecord(p->ev_join, p->stream2));
+        HIPCHK(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+        if (p->n_oct > 1) HIPCHK(hipStreamWaitEvent(p->stream, p->ev_grp1, 0));
+    }
+    hipStream_t fin = p->stream;
     if (p->profile) hipEventRecord(p->ev_last, fin);
-    Counters hc;
-    HIPCHK(hipMemcpyAsync(&hc, p->cnt, sizeof hc, hipMemcpyDeviceToHost, fin));
-    uint32_t hmm[2];
-    HIPCHK(hipMemcpyAsync(hmm, p->mm, sizeof hmm, hipMemcpyDeviceToHost, fin));
-    const double t_enq = tnow();
+    HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, fin));
+    HIPCHK(hipMemcpyAsync(p->hb->mm, p->mm, sizeof p->hb->mm, hipMemcpyDeviceToHost, fin));
+    p->fin = fin;
+    return SIFTMI_OK;
+}
+
+// Wait for the image enqueued last on this plan; returns its record count (records stay on the device).
+int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
+    HIPCHK(hipSetDevice(p->device));
+    hipStream_t fin = p->fin ? p->fin : p->stream;
+    // wait by polling: a blocking hipStreamSynchronize can add wake-up latency to a ~1 ms call
+    static const bool spin = getenv("SIFTMI_NO_SPIN") == nullptr;
+    if (spin) {
+        hipError_t q;
+        while ((q = hipStreamQuery(fin)) == hipErrorNotReady) __builtin_ia32_pause();
+        if (q != hipSuccess) HIPCHK(q);
+    }
     HIPCHK(hipStreamSynchronize(fin));
     HIPCHK(hipStreamSynchronize(p->stream));
+    const Counters &hc = p->hb->c;
+    const uint32_t *hmm = p->hb->mm;
     HIPCHK(hipGetLastError());
-    const double t_sync = tnow();
     {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
         p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
@@ -655,8 +693,27 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     int64_t n = hc.n_out;
     int ovf = hc.overflow;
     if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
-    int rc = SIFTMI_OK;
     p->last_count = n;
+    *n_out = n;
+    if (overflow) *overflow = ovf;
+    return SIFTMI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t image_is_device, siftmi_keypoint *out,
+                          int32_t out_is_device, int64_t capacity, int64_t *n_out, int32_t *overflow) {
+    if (!p || !image || !n_out) return fail(SIFTMI_EINVAL, "null argument");
+    if (capacity > 0 && !out) return fail(SIFTMI_EINVAL, "null output with capacity > 0");
+    *n_out = 0;
+    if (overflow) *overflow = 0;
+    int rc = plan_enqueue(p, image, image_dtype, image_is_device, true);
+    if (rc) return rc;
+    int64_t n = 0;
+    int32_t ovf = 0;
+    if ((rc = plan_wait(p, &n, &ovf))) return rc;
+    hipStream_t fin = p->fin;
     if (out == nullptr && capacity == 0) {
         // count-only call: the records stay on the device until siftmi_plan_fetch()
     } else {
@@ -669,7 +726,6 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     }
     *n_out = n;
     if (overflow) *overflow = ovf;
-    if (htime) fprintf(stderr, "[siftmi] enqueue %.0f us, wait %.0f us, records copy %.0f us\n", t_enq - t_enter, t_sync - t_enq, tnow() - t_sync);
     return rc;
 }
 
@@ -681,6 +737,143 @@ int siftmi_plan_fetch(siftmi_plan *p, siftmi_keypoint *out, int32_t out_is_devic
     HIPCHK(hipMemcpyAsync(out, p->records + first, (size_t)count * sizeof(KpRecord),
                           out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
+    return SIFTMI_OK;
+}
+
+// ---- batched, pipelined keypoints --------------------------------------------------------
+// `lanes` independent plans (own planes, lists and streams) take the images round-robin.  Everything is enqueued
+// without waiting; a lane is only waited for when it is about to be reused, and its records are then parked in a
+// device arena by a device-to-device copy on the lane's own stream.  One device-to-host copy hands the whole batch back.
+}  // extern "C"
+struct siftmi_batch {
+    int device = 0;
+    std::vector<siftmi_plan *> lanes;
+    std::vector<int> lane_image;          // image index in flight on each lane (-1: idle)
+    uint8_t *arena = nullptr;             // parked records of the current batch, image after image
+    size_t arena_cap = 0, arena_used = 0;
+    std::vector<int64_t> counts, offsets;
+};
+extern "C" {
+
+int siftmi_batch_destroy(siftmi_batch *b) {
+    if (!b) return SIFTMI_OK;
+    for (siftmi_plan *p : b->lanes) siftmi_plan_destroy(p);
+    hipSetDevice(b->device);
+    if (b->arena) hipFree(b->arena);
+    delete b;
+    return SIFTMI_OK;
+}
+
+int siftmi_batch_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id, const siftmi_params *params,
+                        int32_t lanes, siftmi_batch **out) {
+    if (!out) return fail(SIFTMI_EINVAL, "null argument");
+    *out = nullptr;
+    if (lanes < 1 || lanes > 64) return fail(SIFTMI_EINVAL, "lanes must be in 1..64, got %d", lanes);
+    siftmi_batch *b = new (std::nothrow) siftmi_batch();
+    if (!b) return fail(SIFTMI_ENOMEM, "host allocation failed");
+    b->device = device_id;
+    for (int l = 0; l < lanes; l++) {
+        siftmi_plan *p = nullptr;
+        int rc = siftmi_plan_create(height, width, in_dtype, device_id, params, 0, &p);
+        if (rc) { std::string keep = g_err; siftmi_batch_destroy(b); g_err = keep; return rc; }
+        // Small frames with many lanes: one stream per lane.  Lanes already overlap each other, and three streams per
+        // lane oversubscribe the hardware queues (512^2, 8 lanes: 0.70 ms per frame with three streams, 0.43 ms with one).
+        if (lanes >= 4 && (int64_t)height * width <= (int64_t)2048 * 2048) p->overlap = false;
+        b->lanes.push_back(p);
+        b->lane_image.push_back(-1);
+    }
+    *out = b;
+    return SIFTMI_OK;
+}
+
+int siftmi_batch_set_params(siftmi_batch *b, const siftmi_params *params) {
+    if (!b) return fail(SIFTMI_EINVAL, "null batch");
+    for (siftmi_plan *p : b->lanes) { int rc = siftmi_plan_set_params(p, params); if (rc) return rc; }
+    return SIFTMI_OK;
+}
+
+int siftmi_batch_info(const siftmi_batch *b, int32_t *lanes, int64_t *bytes_allocated) {
+    if (!b) return fail(SIFTMI_EINVAL, "null batch");
+    if (lanes) *lanes = (int32_t)b->lanes.size();
+    if (bytes_allocated) {
+        int64_t t = (int64_t)b->arena_cap;
+        for (const siftmi_plan *p : b->lanes) t += p->bytes;
+        *bytes_allocated = t;
+    }
+    return SIFTMI_OK;
+}
+
+}  // extern "C"
+namespace {
+// lane `l` has finished its image: learn the count and park the records in the arena (async D->D on the lane's stream)
+int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
+    siftmi_plan *p = b->lanes[l];
+    const int img = b->lane_image[l];
+    if (img < 0) return SIFTMI_OK;
+    int64_t n = 0; int32_t ovf = 0;
+    int rc = plan_wait(p, &n, &ovf);
+    if (rc) return rc;
+    if (ovf && overflow) *overflow = 1;
+    const size_t need = b->arena_used + (size_t)n * sizeof(KpRecord);
+    if (need > b->arena_cap) {
+        size_t cap = b->arena_cap ? b->arena_cap : ((size_t)1 << 22);
+        while (cap < need) cap *= 2;
+        uint8_t *bigger = nullptr;
+        hipError_t e = hipMalloc((void **)&bigger, cap);
+        if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", cap, hipGetErrorString(e));
+        if (b->arena_used) {
+            HIPCHK(hipDeviceSynchronize());               // earlier parking copies may still be in flight
+            HIPCHK(hipMemcpy(bigger, b->arena, b->arena_used, hipMemcpyDeviceToDevice));
+        }
+        if (b->arena) { HIPCHK(hipDeviceSynchronize()); hipFree(b->arena); }
+        b->arena = bigger; b->arena_cap = cap;
+    }
+    if (n > 0)
+        HIPCHK(hipMemcpyAsync(b->arena + b->arena_used, p->records, (size_t)n * sizeof(KpRecord), hipMemcpyDeviceToDevice, p->fin));
+    b->counts[(size_t)img] = n;
+    b->offsets[(size_t)img] = (int64_t)(b->arena_used / sizeof(KpRecord));
+    b->arena_used = need;
+    b->lane_image[l] = -1;
+    return SIFTMI_OK;
+}
+}  // namespace
+extern "C" {
+
+int siftmi_batch_keypoints(siftmi_batch *b, const void *const *images, int32_t n_images, int32_t image_dtype,
+                           int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow) {
+    if (!b || (n_images > 0 && !images) || !counts || !offsets || !total) return fail(SIFTMI_EINVAL, "null argument");
+    if (n_images < 0) return fail(SIFTMI_EINVAL, "negative image count");
+    HIPCHK(hipSetDevice(b->device));
+    if (overflow) *overflow = 0;
+    *total = 0;
+    b->arena_used = 0;
+    b->counts.assign((size_t)n_images, 0);
+    b->offsets.assign((size_t)n_images, 0);
+    if (images_are_device) HIPCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams
+    const size_t L = b->lanes.size();
+    int rc;
+    for (int i = 0; i < n_images; i++) {
+        if (!images[i]) return fail(SIFTMI_EINVAL, "null image %d", i);
+        const size_t l = (size_t)i % L;
+        if ((rc = batch_retire(b, l, overflow))) return rc;
+        if ((rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false))) return rc;
+        b->lane_image[l] = i;
+    }
+    for (size_t l = 0; l < L; l++)
+        if ((rc = batch_retire(b, l, overflow))) return rc;
+    HIPCHK(hipDeviceSynchronize());                            // the parking copies
+    for (int i = 0; i < n_images; i++) { counts[i] = b->counts[(size_t)i]; offsets[i] = b->offsets[(size_t)i]; }
+    *total = (int64_t)(b->arena_used / sizeof(KpRecord));
+    return SIFTMI_OK;
+}
+
+int siftmi_batch_fetch(siftmi_batch *b, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count) {
+    if (!b || (count > 0 && !out)) return fail(SIFTMI_EINVAL, "null argument");
+    if (first < 0 || count < 0 || (size_t)(first + count) * sizeof(KpRecord) > b->arena_used) return fail(SIFTMI_EINVAL, "record range out of bounds");
+    if (count == 0) return SIFTMI_OK;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpy(out, b->arena + (size_t)first * sizeof(KpRecord), (size_t)count * sizeof(KpRecord),
+                     out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return SIFTMI_OK;
 }
 

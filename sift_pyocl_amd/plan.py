@@ -143,13 +143,20 @@ class SiftPlan(object):
             raise RuntimeError("sift_pyocl_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
         self._params = self._current_params()
         self._par_key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
+        self._create(L)
+        self.overflow = False
+        self.debug = []
+
+    def _create(self, L):
+        """Allocate the device side (every buffer of the plan, as plan.py:268-306)."""
         _lib.check(L.siftmi_plan_create(self.shape[0], self.shape[1], self._code, self.device,
                                         C.byref(self._params), self._profile_level, C.byref(self._handle)))
         nbytes = C.c_int64()
         _lib.check(L.siftmi_plan_info(self._handle, None, None, C.byref(nbytes)))
         self.memory = int(nbytes.value)
-        self.overflow = False
-        self.debug = []
+
+    def _destroy(self, L, h):
+        L.siftmi_plan_destroy(h)
 
     # ------------------------------------------------------------------ sizing (plan.py:213-266)
     def _calc_scales(self):
@@ -200,7 +207,7 @@ class SiftPlan(object):
         h = getattr(self, "_handle", None)
         if h:
             try:
-                _lib.lib().siftmi_plan_destroy(h)
+                self._destroy(_lib.lib(), h)
             except Exception:
                 pass
             self._handle = None

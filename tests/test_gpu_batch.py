@@ -1,0 +1,58 @@
+"""GPU parity for the batched, pipelined path: every frame of a batch must come back bit-identical to the
+oracle / to SiftPlan.keypoints of the same frame, whatever the lane count, input residency or frame order."""
+import numpy as np
+import pytest
+
+from util import assert_same_keypoints, smooth_noise, white_noise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lanes", [1, 3, 4])
+def test_batch_equals_oracle_per_frame(siftlib, oracle, lanes):
+    import sift_pyocl_amd as sp
+    shape = (300, 421)
+    frames = [smooth_noise(shape, seed=40 + i, sigma=1.5 + 0.3 * (i % 3)) if i % 2 else white_noise(shape, seed=40 + i) for i in range(7)]
+    bp = sp.BatchPlan(shape=shape, dtype=np.float32, lanes=lanes)
+    got = bp.keypoints_batch(frames)
+    assert len(got) == len(frames)
+    for i, (g, f) in enumerate(zip(got, frames)):
+        assert_same_keypoints(g, oracle.keypoints(f), "frame %d, %d lanes" % (i, lanes))
+    # second batch on the same plan, different order and length: no state leaks between frames or batches
+    got2 = bp.keypoints_batch(frames[::-1][:5])
+    for g, f in zip(got2, frames[::-1][:5]):
+        assert_same_keypoints(g, oracle.keypoints(f), "second batch")
+    assert bp.keypoints_batch([]) == []
+    assert_same_keypoints(bp.keypoints(frames[2]), oracle.keypoints(frames[2]), "batch of one")
+
+
+def test_batch_device_frames_and_typed_frames(siftlib, oracle):
+    import torch
+    import sift_pyocl_amd as sp
+    shape = (1024, 1100)
+    frames = [(smooth_noise(shape, seed=60 + i) * 60000 / 1.0).clip(0, 65535).astype(np.uint16) for i in range(5)]
+    want = [oracle.keypoints(f.astype(np.float32)) for f in frames]
+    bp = sp.BatchPlan(template=frames[0], lanes=2)
+    for g, w in zip(bp.keypoints_batch(frames), want):
+        assert_same_keypoints(g, w, "uint16 host frames")
+    dev = [torch.from_numpy(f.astype(np.int32)).to(torch.int32).cuda() for f in frames]
+    bp32 = sp.BatchPlan(shape=shape, dtype=np.int32, lanes=3)
+    for g, w in zip(bp32.keypoints_batch(dev), want):
+        assert_same_keypoints(g, w, "int32 device frames")
+    with pytest.raises(RuntimeError):
+        bp32.keypoints_batch([dev[0], frames[1].astype(np.int32)])          # mixed residency
+
+
+def test_batch_2048_matches_single_plan(siftlib):
+    """BASELINE.json configs[3] shape: 2048 x 2048 frames; the batch must equal the frame-by-frame plan bit for bit."""
+    import sift_pyocl_amd as sp
+    frames = [white_noise((2048, 2048), seed=80 + i) for i in range(8)]
+    plan = sp.SiftPlan(shape=(2048, 2048), dtype=np.float32)
+    bp = sp.BatchPlan(shape=(2048, 2048), dtype=np.float32, lanes=4)
+    got = bp.keypoints_batch(frames)
+    for i, f in enumerate(frames):
+        assert_same_keypoints(got[i], plan.keypoints(f), "2048 frame %d" % i)
+    from sift_pyocl_amd.batch import keypoints_batch
+    again = keypoints_batch(frames[:3], lanes=2)
+    for i in range(3):
+        assert_same_keypoints(again[i], got[i], "keypoints_batch() helper")

@@ -91,6 +91,9 @@ int siftmi_plan_keypoints(siftmi_plan *plan, const void *image, int32_t image_dt
  * leaves the records on the device; siftmi_plan_fetch copies records [first, first+count) of the last call
  * (to a host buffer, or to a device buffer with out_is_device) -- saves one host-side copy of the result */
 int siftmi_plan_fetch(siftmi_plan *plan, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count);
+/* device address and count of the records of the last call; valid until the next siftmi_plan_keypoints on this plan
+ * (lets MatchPlan consume them in place, as the reference matches pyopencl arrays: alignment.py:155-157,250) */
+int siftmi_plan_records_device(const siftmi_plan *plan, const siftmi_keypoint **records, int64_t *count);
 /* Affine warp with bilinear interpolation of an image of the plan's shape -- the `transform` / `transform_RGB`
  * kernels (openCL/transform.cl:22, :116) as LinearAlign.align launches them (sift-src/alignment.py:325-348).
  *   out[y][x] = bilinear(image, (ty, tx)),  ty = matrix[0]*y + matrix[1]*x + offset[0],

@@ -82,6 +82,7 @@ _SIGNATURES = {
                                            C.c_int64, C.POINTER(C.c_int64)]),
     "siftmi_stage_descriptor": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p]),
+    "siftmi_plan_records_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "siftmi_plan_transform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.POINTER(C.c_double)]),
     "siftmi_stage_shrink": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),

@@ -23,7 +23,7 @@ import numpy
 from . import _lib
 from .match import MatchPlan
 from .plan import SiftPlan
-from .utils import matching_correction
+from .utils import affine_least_squares, matching_correction  # noqa: F401  (matching_correction: reference API)
 
 logger = logging.getLogger("sift.alignment")
 try:
@@ -91,10 +91,24 @@ class LinearAlign(object):
         self.sift = SiftPlan(template=image, device=self.device, profile=self.profile, init_sigma=init_sigma)
         self.ref_kp = self._mask(self.sift.keypoints(image))
         self.match = MatchPlan(device=self.device, profile=self.profile)
+        self._ref_dev = None
+        self._upload_ref()
         self.fill_value = 0
         self.sem = threading.Semaphore()
         self.relative_transfo = None
         self.last_transform_ms = 0.0
+
+    def _upload_ref(self):
+        """Reference keypoints resident on the device (alignment.py:155-157: buffers["ref_kp_gpu"]); needs torch for
+        the allocation, otherwise the host list is sent with every match."""
+        self._ref_dev = None
+        try:
+            import torch
+            if self.ref_kp.size:
+                raw = numpy.ascontiguousarray(self.ref_kp).view(numpy.uint8).reshape(-1)
+                self._ref_dev = torch.from_numpy(raw.copy()).to("cuda:%d" % self.device)
+        except ImportError:
+            pass
 
     def _mask(self, kp):
         if self.ROI is None:
@@ -146,18 +160,32 @@ class LinearAlign(object):
         with self.sem:
             kp = self.sift.keypoints(data)          # uploads `data`; it stays staged on the device for the warp
             logger.debug("mod image keypoints: %s" % kp.size)
-            raw_matching = self.match.match(self.ref_kp, kp, raw_results=True)
-            matching = numpy.recarray(shape=raw_matching.shape, dtype=MatchPlan.dtype_kp)
+            # both lists are matched where they lie in HBM: the reference list uploaded once, the new one still in the plan
+            raw_matching = self.match.match(self._ref_dev if self._ref_dev is not None else self.ref_kp,
+                                            self.sift.device_records() if kp.size else kp, raw_results=True)
             len_match = raw_matching.shape[0]
             if len_match == 0:
                 logger.warning("No matching keypoints")
                 return
-            matching[:, 0] = self.ref_kp[raw_matching[:, 0]]
-            matching[:, 1] = kp[raw_matching[:, 1]]
+            # Only (x, y, scale, angle) of the matched keypoints enter the fit: gather those 16 bytes per keypoint
+            # instead of the 144-byte records; the `matching` recarray of the reference (alignment.py:254-259) is
+            # built lazily, for ORSA and for return_all.
+            g0 = self._xysa(self.ref_kp)[raw_matching[:, 0]]
+            g1 = self._xysa(kp)[raw_matching[:, 1]]
+            matching = None
+            ref_kp_used = self.ref_kp
+
+            def full_matching():
+                m = numpy.recarray(shape=raw_matching.shape, dtype=MatchPlan.dtype_kp)
+                m[:, 0] = ref_kp_used[raw_matching[:, 0]]
+                m[:, 1] = kp[raw_matching[:, 1]]
+                return m
 
             if orsa:
                 if feature:
-                    matching = feature.sift_orsa(matching, self.shape, 1)
+                    matching = feature.sift_orsa(full_matching(), self.shape, 1)
+                    g0 = numpy.stack([matching[:, 0].x, matching[:, 0].y, matching[:, 0].scale, matching[:, 0].angle], axis=1)
+                    g1 = numpy.stack([matching[:, 1].x, matching[:, 1].y, matching[:, 1].scale, matching[:, 1].angle], axis=1)
                 else:
                     logger.warning("feature is not available. No ORSA filtering")
 
@@ -166,19 +194,19 @@ class LinearAlign(object):
                     logger.debug("Shift Only mode: Common keypoints: %s" % len_match)
                 else:
                     logger.warning("Shift Only mode: Common keypoints: %s" % len_match)
-                dx = matching[:, 1].x - matching[:, 0].x
-                dy = matching[:, 1].y - matching[:, 0].y
+                dx = g1[:, 0] - g0[:, 0]
+                dy = g1[:, 1] - g0[:, 1]
                 matrix = numpy.identity(2, dtype=numpy.float32)
                 offset = numpy.array([+numpy.median(dy), +numpy.median(dx)], numpy.float32)
             else:
                 logger.debug("Common keypoints: %s" % len_match)
-                matrix, offset = self._affine(matching)
+                matrix, offset = self._affine(g0, g1)
             if double_check and (len_match >= 3 * 6):
                 logger.warning("Validating keypoints, %s,%s" % (matrix, offset))
-                dx = matching[:, 1].x - matching[:, 0].x
-                dy = matching[:, 1].y - matching[:, 0].y
-                dangle = matching[:, 1].angle - matching[:, 0].angle
-                dscale = numpy.log(matching[:, 1].scale / matching[:, 0].scale)
+                dx = g1[:, 0] - g0[:, 0]
+                dy = g1[:, 1] - g0[:, 1]
+                dangle = g1[:, 3] - g0[:, 3]
+                dscale = numpy.log(g1[:, 2] / g0[:, 2])
                 distance = numpy.sqrt(dx * dx + dy * dy)
                 outlayer = numpy.zeros(distance.shape, numpy.int8)
                 outlayer += abs((distance - distance.mean()) / distance.std()) > 4
@@ -186,10 +214,11 @@ class LinearAlign(object):
                 outlayer += abs((dscale - dscale.mean()) / dscale.std()) > 4
                 outlayersum = outlayer.sum()
                 if outlayersum > 0 and not numpy.isinf(outlayersum):
-                    matching2 = matching[outlayer == 0]
-                    matrix, offset = self._affine(matching2)
+                    keep = outlayer == 0
+                    matrix, offset = self._affine(g0[keep], g1[keep])
             if relative:  # update stable part to perform a relative alignment
                 self.ref_kp = self._mask(kp)
+                self._upload_ref()
                 transfo = numpy.zeros((3, 3), dtype=numpy.float64)
                 transfo[:2, :2] = matrix
                 transfo[0, 2] = offset[0]
@@ -204,18 +233,25 @@ class LinearAlign(object):
             result = self.transform(matrix, offset, image=None, fill=self.sift.minmax()[0], mode=1)
 
         if return_all:
-            corr = numpy.dot(matrix, numpy.vstack((matching[:, 0].y, matching[:, 0].x))).T + offset.T - \
-                numpy.vstack((matching[:, 1].y, matching[:, 1].x)).T
+            corr = numpy.dot(matrix, numpy.vstack((g0[:, 1], g0[:, 0]))).T + offset.T - numpy.vstack((g1[:, 1], g1[:, 0])).T
             rms = numpy.sqrt((corr * corr).sum(axis=-1).mean())
+            if matching is None:
+                matching = full_matching()
             return {"result": result, "keypoint": kp, "matching": matching, "offset": offset, "matrix": matrix, "rms": rms}
         return result
 
     __call__ = align
 
     @staticmethod
-    def _affine(matching):
+    def _xysa(kp):
+        """(n, 4) float32 view of (x, y, scale, angle) of a keypoint array (no copy for contiguous records)"""
+        a = numpy.ascontiguousarray(kp)
+        return a.view(numpy.uint8).reshape(a.shape[0], 144)[:, :16].view(numpy.float32)
+
+    @staticmethod
+    def _affine(g0, g1):
         """alignment.py:279-283: (a..f) of matching_correction -> the (y, x)-ordered matrix / offset of the kernel"""
-        t = matching_correction(matching)
+        t = affine_least_squares(g0[:, 0], g0[:, 1], g1[:, 0], g1[:, 1])
         offset = numpy.array([t[5], t[2]], dtype=numpy.float32)
         matrix = numpy.empty((2, 2), dtype=numpy.float32)
         matrix[0, 0], matrix[0, 1] = t[4], t[3]

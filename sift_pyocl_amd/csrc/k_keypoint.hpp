@@ -60,6 +60,7 @@ struct Counters {
     int grp_out_start[SIFT_GROUPS + 1]; // record-list range of each group, closed by mark_group_kernel
     int grp_out_end[SIFT_GROUPS + 1];
     int n_cand[SIFT_MAX_OCTAVES];       // candidates per octave
+    uint32_t mm[2];                     // order-encoded min / max of the input (k_pyramid.hpp), read back with the counters
 };
 
 // where the six planes of every octave live: plane(o, s) = base + off[o] + s * W[o] * H[o]
@@ -80,7 +81,7 @@ __global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_c
 
 __global__ void begin_image_kernel(Counters *c) {
     const int t = threadIdx.x;
-    if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; }
+    if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; c->mm[0] = 0xffffffffu; c->mm[1] = 0u; }
     if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; }
     if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
 }

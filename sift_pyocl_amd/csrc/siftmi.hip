@@ -96,6 +96,7 @@ size_t dtype_size(int dt) {
 }  // namespace
 
 struct siftmi_plan {
+    void *chain = nullptr;        // open light-profile bracket (a Scope, profile == 1)
     int device = 0;
     hipStream_t stream = nullptr;
     int H = 0, W = 0, dtype = 0;
@@ -118,7 +119,7 @@ struct siftmi_plan {
     int raw_dtype = -1;           // dtype of the image currently staged in `raw` (-1: none)
     hipStream_t fin = nullptr;    // stream on which the last enqueued image ends
     hipEvent_t ev_join = nullptr;
-    struct HostBack { Counters c; uint32_t mm[2]; } *hb = nullptr;   // pinned read-back block (one async D->H + one wait per image)
+    struct HostBack { Counters c; } *hb = nullptr;   // pinned read-back block (one async D->H + one wait per image)
     void *warp_in = nullptr, *warp_out = nullptr;   // siftmi_plan_transform staging, grown on demand
     size_t warp_in_bytes = 0, warp_out_bytes = 0;
     hipEvent_t ev_wa = nullptr, ev_wb = nullptr;
@@ -361,7 +362,8 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
         Scope sc(p, lab, false, 0, st);
         static const int ori_blocks = getenv("SIFTMI_ORI_BLOCKS") ? atoi(getenv("SIFTMI_ORI_BLOCKS")) : 1024;   // dev knob
-        hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), 0, st, tab, p->par.ori_sigma,
+        static const int ori_pad = getenv("SIFTMI_ORI_PAD") ? atoi(getenv("SIFTMI_ORI_PAD")) : 0;   // dev knob
+        hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
                            (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap);
     }
     hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap);
@@ -370,7 +372,8 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         snprintf(lab, sizeof lab, "descriptors group %d", group);
         Scope sc(p, lab, false, 0, st);
         static const int desc_blocks = getenv("SIFTMI_DESC_BLOCKS") ? atoi(getenv("SIFTMI_DESC_BLOCKS")) : 2048;   // dev knob
-        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), 0, st, tab,
+        static const int desc_pad = getenv("SIFTMI_DESC_PAD") ? atoi(getenv("SIFTMI_DESC_PAD")) : 0;   // dev knob: extra LDS per block
+        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                            (const float4 *)p->okp, (const int *)p->oaux, p->cnt, group, 0, 0, kcap, p->records);
     }
 }
@@ -435,7 +438,11 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     p->kpsize = (int64_t)(N / (size_t)params->pix_per_kp);   // plan.py:243
     if (p->kpsize < 1) p->kpsize = 1;
     int rc = SIFTMI_OK;
-    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    // SIFTMI_PRIO=1 (dev knob): pyramid and later-octave streams above the octave-0 detection stream
+    static const bool prio = getenv("SIFTMI_PRIO") != nullptr;
+    int prio_lo = 0, prio_hi = 0;
+    if (prio) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t e = prio ? hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete p; return fail(SIFTMI_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     {
         size_t off = 0;
@@ -443,8 +450,8 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
         if (p->n_oct == 0) { p->oct_off.push_back(0); off = 6 * N; p->ow.assign(1, width); p->oh.assign(1, height); }
         rc = p->alloc(&p->planes, off * sizeof(float));
     }
-    if (!rc && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
-    if (!rc && hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
+    if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
+    if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
     if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_grp1, hipEventDisableTiming) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
     p->overlap = getenv("SIFTMI_SINGLE_STREAM") == nullptr;
@@ -456,8 +463,9 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc) rc = p->alloc(&p->tmp, N * sizeof(float));
     if (!rc) rc = p->alloc(&p->raw, N * (dtype_size(in_dtype) > 4 ? dtype_size(in_dtype) : 4));
     if (!rc && in_dtype != SIFTMI_F32) rc = p->alloc(&p->conv, N * sizeof(float));
-    if (!rc) rc = p->alloc(&p->mm, 2 * sizeof(uint32_t));
+
     if (!rc) rc = p->alloc(&p->cnt, sizeof(Counters));
+    if (!rc) p->mm = p->cnt->mm;   // device address of the min/max slots inside the counter block
     if (!rc) rc = p->alloc(&p->cand, (size_t)p->kpsize * sizeof(float4));
     if (!rc) rc = p->alloc(&p->kp, (size_t)p->kpsize * sizeof(float4));
     if (!rc) rc = p->alloc(&p->kp_scale, (size_t)p->kpsize * sizeof(int));
@@ -572,7 +580,6 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
     static const int mm_blocks = getenv("SIFTMI_MM_BLOCKS") ? atoi(getenv("SIFTMI_MM_BLOCKS")) : 256;
     {
         Scope sc(p, "max_min");
-        hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, p->stream, p->mm);
         if (fused_in) {
             SIFTMI_TYPED_DISPATCH(image_dtype, hipLaunchKernelGGL(minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, mm_blocks)),
                                                                    dim3(256), 0, p->stream, src, (int64_t)N, p->mm));
@@ -583,12 +590,20 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
     }
     float *base0 = p->plane(0, 0);
     if (p->have_init) {
-        Scope sc(p, "normalize + initial blur", true, (double)N, nullptr, 0);
+        // light profiling: ONE event pair around the six full-resolution blur launches (initial + five scales of
+        // octave 0); it is closed in enqueue_body.  Event records between kernels cost ~4-10 us each.
+        Scope *sc = nullptr;
+        if (p->profile == 1) {
+            Scope *ch = new Scope(p, "Blur octave 0: initial + scales 0-4 (one bracket)", true, 6.0 * (double)N, nullptr, 0);
+            if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 6;
+            p->chain = ch;
+        } else sc = new Scope(p, "normalize + initial blur", true, (double)N, nullptr, 0);
         if (fused_in) {
             SIFTMI_TYPED_DISPATCH(image_dtype, launch_init_blur_dt<DT>(p->stream, src, base0, p->W, p->H, p->taps[5], p->mm));
         } else {
             launch_blur(p, f32src, base0, p->W, p->H, p->taps[5], true);
         }
+        delete sc;
     } else {
         Scope sc(p, "normalize");
         const dim3 g(grid_for((int64_t)N, 256, 4096));
@@ -618,12 +633,13 @@ int enqueue_body(siftmi_plan *p) {
     for (int oct = 0; oct < p->n_oct; oct++) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
         if (p->profile == 1) {
-            // light profiling: ONE event pair around the five back-to-back blur launches of octave 0 (event
-            // records between kernels cost ~4 us each and keep consecutive launches from overlapping)
-            Scope *chain = (oct == 0) ? new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0) : nullptr;
-            if (chain && chain->idx != (size_t)-1) p->events[chain->idx].launches = 5;
+            if (oct == 0 && !p->chain) {          // no initial blur: the bracket opens here, five launches
+                Scope *ch = new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0);
+                if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
+                p->chain = ch;
+            }
             for (int s = 0; s < 5; s++) launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
-            delete chain;
+            if (oct == 0) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }
         } else {
             for (int s = 0; s < 5; s++) {
                 snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
@@ -631,20 +647,20 @@ int enqueue_body(siftmi_plan *p) {
                 launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
             }
         }
+        // group 0 = octave 0 on stream2, described right away; group 1 = every later octave on stream3: it
+        // starts once group 0's orientation pass has frozen its ranges and overlaps group 0's descriptors
+        hipStream_t dst = !p->overlap ? p->stream : (oct == 0 ? p->stream2 : p->stream3);
+        if (p->overlap) {
+            HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], p->stream));     // before the shrink: detection need not wait for it
+            if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
+            HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
+        }
         if (oct < p->n_oct - 1) {
             const int SW = p->ow[(size_t)oct + 1], SH = p->oh[(size_t)oct + 1];
             snprintf(lab, sizeof lab, "shrink %d", oct);
             Scope sc(p, lab);
             hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, p->stream,
                                (const float *)p->plane(oct, 3), p->plane(oct + 1, 0), W, SW, SH);
-        }
-        // group 0 = octave 0 on stream2, described right away; group 1 = every later octave on stream3: it
-        // starts once group 0's orientation pass has frozen its ranges and overlaps group 0's descriptors
-        hipStream_t dst = !p->overlap ? p->stream : (oct == 0 ? p->stream2 : p->stream3);
-        if (p->overlap) {
-            HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], p->stream));
-            if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
-            HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
         }
         launch_detect_octave(p, oct, dst);
         if (oct == 0) launch_describe_group(p, 0, dst);
@@ -665,7 +681,6 @@ int enqueue_body(siftmi_plan *p) {
     hipStream_t fin = p->stream;
     if (p->profile) hipEventRecord(p->ev_last, fin);
     HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, fin));
-    HIPCHK(hipMemcpyAsync(p->hb->mm, p->mm, sizeof p->hb->mm, hipMemcpyDeviceToHost, fin));
     p->fin = fin;
     return SIFTMI_OK;
 }
@@ -684,7 +699,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     HIPCHK(hipStreamSynchronize(fin));
     HIPCHK(hipStreamSynchronize(p->stream));
     const Counters &hc = p->hb->c;
-    const uint32_t *hmm = p->hb->mm;
+    const uint32_t *hmm = p->hb->c.mm;
     HIPCHK(hipGetLastError());
     {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
@@ -874,6 +889,13 @@ int siftmi_batch_fetch(siftmi_batch *b, siftmi_keypoint *out, int32_t out_is_dev
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipMemcpy(out, b->arena + (size_t)first * sizeof(KpRecord), (size_t)count * sizeof(KpRecord),
                      out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_records_device(const siftmi_plan *p, const siftmi_keypoint **records, int64_t *count) {
+    if (!p || !records) return fail(SIFTMI_EINVAL, "null argument");
+    *records = reinterpret_cast<const siftmi_keypoint *>(p->records);
+    if (count) *count = p->last_count;
     return SIFTMI_OK;
 }
 

@@ -46,6 +46,15 @@ def _pointer_of(image):
     return arr.ctypes.data, 0, arr.dtype, arr.shape, arr
 
 
+class _DeviceRecords(object):
+    """Borrowed view of n 144-byte keypoint records in HBM (see SiftPlan.device_records)."""
+
+    def __init__(self, ptr, n, owner):
+        self._owner = owner
+        self.shape = (n * 144,)
+        self.__cuda_array_interface__ = {"shape": (n * 144,), "typestr": "|u1", "data": (ptr, True), "version": 2, "strides": None}
+
+
 class SiftPlan(object):
     """Plan to compute SIFT keypoints of images of one shape and type.
 
@@ -264,6 +273,15 @@ class SiftPlan(object):
         return output
 
     __call__ = keypoints
+
+    def device_records(self):
+        """The records of the last keypoints() call where they lie on the device (no copy): an object with
+        ``__cuda_array_interface__`` (uint8, n * 144 bytes), accepted by ``MatchPlan.match``.  Valid until the next
+        call on this plan -- the reference's equivalent is matching ``pyopencl.array`` keypoints in place."""
+        ptr = C.c_void_p()
+        n = C.c_int64()
+        _lib.check(_lib.lib().siftmi_plan_records_device(self._handle, C.byref(ptr), C.byref(n)))
+        return _DeviceRecords(ptr.value or 0, int(n.value), self)
 
     def minmax(self):
         """(min, max) of the last processed image (buffers["min"], buffers["max"] in the reference)."""

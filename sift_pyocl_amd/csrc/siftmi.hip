@@ -767,6 +767,7 @@ struct siftmi_batch {
     uint8_t *arena = nullptr;             // parked records of the current batch, image after image
     size_t arena_cap = 0, arena_used = 0;
     std::vector<int64_t> counts, offsets;
+    int64_t retired = 0, batch_size = 0;  // frames retired so far / frames in the current batch
 };
 extern "C" {
 
@@ -831,8 +832,11 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     if (ovf && overflow) *overflow = 1;
     const size_t need = b->arena_used + (size_t)n * sizeof(KpRecord);
     if (need > b->arena_cap) {
+        // grow to the projected size of the whole batch (records so far / frames retired x frames of the batch,
+        // +25 %), so that a batch regrows the arena at most a couple of times: each regrow drains the device
         size_t cap = b->arena_cap ? b->arena_cap : ((size_t)1 << 22);
-        while (cap < need) cap *= 2;
+        const size_t projected = (size_t)((double)need / (double)(b->retired + 1) * (double)b->batch_size * 1.25);
+        while (cap < need || cap < projected) cap *= 2;
         uint8_t *bigger = nullptr;
         hipError_t e = hipMalloc((void **)&bigger, cap);
         if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", cap, hipGetErrorString(e));
@@ -848,6 +852,7 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     b->counts[(size_t)img] = n;
     b->offsets[(size_t)img] = (int64_t)(b->arena_used / sizeof(KpRecord));
     b->arena_used = need;
+    b->retired++;
     b->lane_image[l] = -1;
     return SIFTMI_OK;
 }
@@ -862,6 +867,7 @@ int siftmi_batch_keypoints(siftmi_batch *b, const void *const *images, int32_t n
     if (overflow) *overflow = 0;
     *total = 0;
     b->arena_used = 0;
+    b->retired = 0; b->batch_size = n_images;
     b->counts.assign((size_t)n_images, 0);
     b->offsets.assign((size_t)n_images, 0);
     if (images_are_device) HIPCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams

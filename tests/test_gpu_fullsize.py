@@ -97,3 +97,19 @@ def test_match_100k_properties(siftlib, oracle):
     got = pairs[np.isin(pairs[:, 0], sl)].copy()
     got[:, 0] = np.searchsorted(sl, got[:, 0])
     assert total == len(got) and np.array_equal(sort_rows(got), sort_rows(exp))
+
+
+def test_16384_white_noise_bit_exact(siftlib, oracle):
+    """BASELINE.json configs[2]: 16384 x 16384 fp32 on one MI355X (1 GiB frame, 8.5 GB of planes): bit-exact against
+    the oracle at 3 octaves (the oracle needs ~20 s on the host cores), plus bounds on the full-octave run."""
+    import sift_pyocl_amd as sp
+    img = white_noise((16384, 16384), seed=2)
+    plan = sp.SiftPlan(template=img, octave_max=3)
+    got = plan.keypoints(img)
+    assert 150000 < len(got) < 200000 and not plan.overflow
+    assert_same_keypoints(got, oracle.keypoints(img, oracle.default_params(octave_max=3)), "16384 white, 3 octaves")
+    del plan
+    full = sp.SiftPlan(template=img)
+    assert full.octave_max == 11
+    allk = full.keypoints(img)
+    assert {r.tobytes() for r in got}.issubset({r.tobytes() for r in allk})

@@ -43,7 +43,7 @@ run(4096, "smooth", 0, 10)
 if "--skip-16k" not in sys.argv:
     run(16384, "white", 0, 3)
     run(16384, "white", 3, 3)
-# C4 on one GPU: 64 images 2048x2048 through the batch path (no process group -> plain loop)
+# C4 on one GPU: 64 images 2048x2048: frame-by-frame SiftPlan loop, then the pipelined BatchPlan (8 lanes)
 imgs = [np.random.default_rng(i).random((2048, 2048), dtype=np.float32) for i in range(64)]
 dev = [torch.from_numpy(i).cuda() for i in imgs]
 plan = sp.SiftPlan(shape=(2048, 2048), dtype=np.float32)
@@ -51,4 +51,12 @@ keypoints_batch(dev[:4], plan=plan)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = keypoints_batch(dev, plan=plan)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("C4 on ONE GPU: 64 x 2048^2 device-resident: %.2f ms total, %.3f ms/image, %.0f Mpix/s, %d keypoints" % (1e3 * dt, 1e3 * dt / 64, 64 * 2048 * 2048 / 1e6 / dt, sum(len(r) for r in res)))
+print("C4 on ONE GPU, SiftPlan loop : 64 x 2048^2 device-resident: %.2f ms total, %.3f ms/image, %.0f Mpix/s, %d keypoints" % (1e3 * dt, 1e3 * dt / 64, 64 * 2048 * 2048 / 1e6 / dt, sum(len(r) for r in res)))
+del plan
+bp = sp.BatchPlan(shape=(2048, 2048), dtype=np.float32, lanes=8)
+bp.keypoints_batch(dev[:8])
+for name, frames in (("device-resident", dev), ("host (numpy)", imgs)):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = bp.keypoints_batch(frames)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("C4 on ONE GPU, BatchPlan(8)  : 64 x 2048^2 %s: %.2f ms total, %.3f ms/image, %.0f Mpix/s, %d keypoints" % (name, 1e3 * dt, 1e3 * dt / 64, 64 * 2048 * 2048 / 1e6 / dt, sum(len(r) for r in res)))

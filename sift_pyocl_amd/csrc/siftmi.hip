@@ -438,8 +438,9 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     p->kpsize = (int64_t)(N / (size_t)params->pix_per_kp);   // plan.py:243
     if (p->kpsize < 1) p->kpsize = 1;
     int rc = SIFTMI_OK;
-    // SIFTMI_PRIO=1 (dev knob): pyramid and later-octave streams above the octave-0 detection stream
-    static const bool prio = getenv("SIFTMI_PRIO") != nullptr;
+    // The pyramid stream and the later-octave stream get a higher priority than the octave-0 detection stream, whose
+    // long orientation / descriptor kernels would otherwise win every dispatch slot (measured: -1 % per image).
+    static const bool prio = getenv("SIFTMI_NO_PRIO") == nullptr;
     int prio_lo = 0, prio_hi = 0;
     if (prio) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hipError_t e = prio ? hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);

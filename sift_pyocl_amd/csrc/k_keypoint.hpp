@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
 // Waves of a block are independent (4 keypoints per 256-thread block); latency is hidden by
 // occupancy instead of by barriers.
 struct DescWaveLds {
-    uint4 binfo[128];             // per bin: {mask lo, mask hi, pool base, -} : 64-bit mask of contributing lanes
+    // per bin: 64-bit mask of contributing lanes (two words) and the pool base, as three separate arrays: with one
+    // 16-byte record per bin every access had a 4-bank stride (48 % of the kernel's LDS cycles were bank conflicts)
+    unsigned int mlo[128], mhi[128], mbase[128];
     float pool[8 * 64];           // contribution values, grouped by bin, in lane (= raster) order inside a bin
     int pool_cnt;
     int sij[128];                 // packed (ii + 32768) | (jj + 32768) << 16
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(OctaveTable tab, const 
     if (cnt) {
         start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity);
     }
-    L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u); L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+    L.mlo[lane] = 0u; L.mhi[lane] = 0u; L.mlo[lane + 64] = 0u; L.mhi[lane + 64] = 0u;
     if (lane == 0) L.pool_cnt = 0;
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(OctaveTable tab, const 
                                 if (ok && !dup) {
                                     cbin[n8] = (rb * 4 + cb) * 8 + ob;
                                     cval[n8] = cw * (e == 0 ? 1.0f - of : of);
-                                    atomicOr(reinterpret_cast<unsigned int *>(&L.binfo[cbin[n8]]) + word, bit);
+                                    atomicOr((word ? L.mhi : L.mlo) + cbin[n8], bit);
                                 }
                             }
                         }
@@ -362,21 +364,21 @@ __global__ __launch_bounds__(256) void descriptor_kernel(OctaveTable tab, const 
             //         segment base + (number of lower lanes contributing to the same bin); (c) the owner adds
             //         its segment front to back: ascending lane == raster order of the samples.
             if (!(ABL(1) || ABL(3))) {
-                uint4 ia = L.binfo[lane], ib = L.binfo[lane + 64];
+                const uint2 ia = make_uint2(L.mlo[lane], L.mhi[lane]), ib = make_uint2(L.mlo[lane + 64], L.mhi[lane + 64]);
                 const int cnta = __popc(ia.x) + __popc(ia.y), cntb = __popc(ib.x) + __popc(ib.y);
                 int base_a = 0;
                 if (cnta + cntb) base_a = atomicAdd(&L.pool_cnt, cnta + cntb);
                 const int base_b = base_a + cnta;
-                if (cnta) L.binfo[lane].z = (unsigned)base_a;
-                if (cntb) L.binfo[lane + 64].z = (unsigned)base_b;
+                if (cnta) L.mbase[lane] = (unsigned)base_a;
+                if (cntb) L.mbase[lane + 64] = (unsigned)base_b;
                 __builtin_amdgcn_wave_barrier();
                 const unsigned lo_mask = (lane < 32) ? ((1u << lane) - 1u) : 0xffffffffu;
                 const unsigned hi_mask = (lane < 32) ? 0u : ((1u << (lane - 32)) - 1u);
 #pragma unroll
                 for (int n8 = 0; n8 < 8; n8++)
                     if (cbin[n8] >= 0) {
-                        const uint4 bi = L.binfo[cbin[n8]];
-                        L.pool[bi.z + __popc(bi.x & lo_mask) + __popc(bi.y & hi_mask)] = cval[n8];
+                        const int b = cbin[n8];
+                        L.pool[L.mbase[b] + __popc(L.mlo[b] & lo_mask) + __popc(L.mhi[b] & hi_mask)] = cval[n8];
                     }
                 __builtin_amdgcn_wave_barrier();
                 const int nmax = max(cnta, cntb);
@@ -392,11 +394,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(OctaveTable tab, const 
                     for (int u = 0; u < 4; u++) { acc0 = acc0 + va[u]; acc1 = acc1 + vb[u]; }
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (cnta) L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u);
-                if (cntb) L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+                if (cnta) { L.mlo[lane] = 0u; L.mhi[lane] = 0u; }
+                if (cntb) { L.mlo[lane + 64] = 0u; L.mhi[lane + 64] = 0u; }
                 if (lane == 0) L.pool_cnt = 0;
             } else {
-                L.binfo[lane] = make_uint4(0u, 0u, 0u, 0u); L.binfo[lane + 64] = make_uint4(0u, 0u, 0u, 0u);
+                L.mlo[lane] = 0u; L.mhi[lane] = 0u; L.mlo[lane + 64] = 0u; L.mhi[lane + 64] = 0u;
             }
             __builtin_amdgcn_wave_barrier();
             // ---- drop the consumed entries, keep order

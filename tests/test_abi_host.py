@@ -45,6 +45,10 @@ def test_no_gpu_fails_loudly(L):
         sp.SiftPlan((64, 64), np.float32)
     with pytest.raises(RuntimeError):
         sp.MatchPlan()
+    with pytest.raises(RuntimeError):
+        sp.BatchPlan(shape=(64, 64), dtype=np.float32, lanes=2)
+    with pytest.raises(RuntimeError):
+        sp.LinearAlign(np.zeros((64, 64), np.float32))
     from sift_pyocl_amd import _lib
     h = C.c_void_p()
     par = _lib.Params(init_sigma=1.6, peak_thresh=3.4, edge_thresh0=0.08, edge_thresh=0.06, ori_sigma=1.5,
@@ -53,6 +57,32 @@ def test_no_gpu_fails_loudly(L):
     assert b"device" in L.siftmi_last_error().lower()
     out = np.empty((4, 4), np.float32)
     assert L.siftmi_stage_blur(0, out.ctypes.data, out.ctypes.data, 4, 4, out.ctypes.data, 3) != 0
+    hb = C.c_void_p()
+    assert L.siftmi_batch_create(64, 64, 0, 0, C.byref(par), 2, C.byref(hb)) == _lib.EDEVICE and not hb.value
+    hm = C.c_void_p()
+    assert L.siftmi_match_create(100, 0, 0, C.byref(hm)) == _lib.EDEVICE and not hm.value
+
+
+def test_matching_correction_is_a_least_squares_fit():
+    """utils.matching_correction (completed: the reference's version has no solve, utils.py:156-189) against numpy.linalg.lstsq"""
+    from sift_pyocl_amd.utils import affine_least_squares, matching_correction
+    from sift_pyocl_amd.match import MatchPlan
+    rng = np.random.default_rng(3)
+    n = 400
+    m = np.zeros((n, 2), MatchPlan.dtype_kp).view(np.recarray)
+    x = rng.random(n) * 4000; y = rng.random(n) * 3000
+    m.x[:, 0] = x; m.y[:, 0] = y
+    m.x[:, 1] = 1.01 * x + 0.02 * y + 3 + rng.normal(0, 0.2, n); m.y[:, 1] = -0.015 * x + 0.99 * y - 4 + rng.normal(0, 0.2, n)
+    X = np.zeros((2 * n, 6)); rhs = np.zeros(2 * n)
+    X[::2, 0] = m.x[:, 0]; X[::2, 1] = m.y[:, 0]; X[::2, 2] = 1; X[1::2, 3] = m.x[:, 0]; X[1::2, 4] = m.y[:, 0]; X[1::2, 5] = 1
+    rhs[::2] = m.x[:, 1]; rhs[1::2] = m.y[:, 1]
+    want = np.linalg.lstsq(X, rhs, rcond=None)[0]
+    got = matching_correction(m)
+    assert np.allclose(got, want, rtol=0, atol=1e-9)
+    assert np.allclose(got, [1.01, 0.02, 3, -0.015, 0.99, -4], atol=0.05)
+    # degenerate (collinear) input falls back to the minimum-norm solution instead of dividing by zero
+    t = affine_least_squares([0, 1, 2, 3], [0, 1, 2, 3], [1, 2, 3, 4], [2, 3, 4, 5])
+    assert np.all(np.isfinite(t)) and np.allclose([t[0] * 2 + t[1] * 2 + t[2], t[3] * 2 + t[4] * 2 + t[5]], [3, 4])
 
 
 def test_host_gaussian_taps_match_oracle(L, oracle):

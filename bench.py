@@ -72,6 +72,31 @@ def cpu_baseline(size, octaves):
                       "oracle/sift_oracle.c with OpenMP on %d threads (%.1f s wall)" % (reps, size, size, octaves, threads, el)}
 
 
+def cpu_reference_kernels(octaves, size=1024):
+    """The reference's OWN OpenCL-CPU kernels, compiled natively into oracle/_ref (when that build travelled with the
+    snapshot), driven serially on one host thread over a bounded sample.  None if the library is absent."""
+    try:
+        from oracle import pyref
+        if not pyref.available():
+            return None
+        img = make_image(0, size)
+        pyref.keypoints(make_image(1, 256), octave_max=octaves)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            k = pyref.keypoints(img, octave_max=octaves)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 4.0 or reps >= 4:
+                break
+        return {"value": round(reps * size * size / 1e6 / el, 3), "unit": "Mpix/s", "cores": 1, "kind": "reference",
+                "keypoints_per_s": round(reps * len(k) / el, 1),
+                "sample": "%d x the reference's own kernels (openCL/*.cl built natively, oracle/_ref) over one %dx%d fp32 "
+                          "white-noise image, %d octaves, serial NDRange on 1 thread (%.1f s wall)" % (reps, size, size, octaves, el)}
+    except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
+        return {"error": str(exc)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +239,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(size, n_oct)
+            ref = cpu_reference_kernels(n_oct)
+            if ref is not None:
+                out["cpu_baseline_reference_kernels"] = ref
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -21,19 +21,34 @@ namespace siftk {
 struct KpRecord { float x, y, scale, angle; uint8_t desc[128]; };   // == siftmi_keypoint
 static_assert(sizeof(KpRecord) == 144, "record layout");
 
-// image.cl:58-77
-__device__ __forceinline__ void gradient_at(const float *__restrict__ I, int x, int y, int W, int H,
-                                            float &mag, float &ori) {
+// image.cl:58-77, split in two so that the four pixel loads of the NEXT batch of samples can be in flight while the
+// current batch is evaluated (the per-keypoint kernels spent half their time in s_waitcnt on exactly these loads).
+// gx = sx * (xa - xb), gy = sy * (ya - yb) with sx, sy = 2 on the image border (one-sided difference), else 1.
+struct GradTaps { float xa, xb, ya, yb; bool bx, by; };
+
+__device__ __forceinline__ GradTaps gradient_fetch(const float *__restrict__ I, int x, int y, int W, int H) {
     const size_t pos = (size_t)y * W + x;
-    float gx, gy;
-    if (x == 0) gx = 2.0f * (I[pos + 1] - I[pos]);
-    else if (x == W - 1) gx = 2.0f * (I[pos] - I[pos - 1]);
-    else gx = I[pos + 1] - I[pos - 1];
-    if (y == 0) gy = 2.0f * (I[pos] - I[pos + W]);
-    else if (y == H - 1) gy = 2.0f * (I[pos - W] - I[pos]);
-    else gy = I[pos - W] - I[pos + W];
+    GradTaps t;
+    t.bx = (x == 0) || (x == W - 1);
+    t.by = (y == 0) || (y == H - 1);
+    t.xa = I[x == W - 1 ? pos : pos + 1];
+    t.xb = I[x == 0 ? pos : pos - 1];
+    t.ya = I[y == 0 ? pos : pos - W];
+    t.yb = I[y == H - 1 ? pos : pos + W];
+    return t;
+}
+
+__device__ __forceinline__ void gradient_eval(const GradTaps &t, float &mag, float &ori) {
+    float gx = t.xa - t.xb, gy = t.ya - t.yb;
+    if (t.bx) gx = 2.0f * gx;
+    if (t.by) gy = 2.0f * gy;
     mag = sqrtf(gx * gx + gy * gy);
     ori = siftmath::atan2f_(-gy, gx);
+}
+
+__device__ __forceinline__ void gradient_at(const float *__restrict__ I, int x, int y, int W, int H,
+                                            float &mag, float &ori) {
+    gradient_eval(gradient_fetch(I, x, y, W, H), mag, ori);
 }
 
 // exact idx / d for 0 <= idx < 2^22, 1 <= d < 2^12 (inv = 1.0f / d)
@@ -125,17 +140,31 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         const int total = (wc > 0 && hr > 0) ? wc * hr : 0;
         const float inv_wc = 1.0f / (float)max(wc, 1);
         float h = 0.0f;                  // lane b < 36 owns hist[b]
-        for (int base = 0; base < total; base += 64) {
+        // sample position of this lane in the batch starting at `base`; the loads of batch b+1 are issued before
+        // batch b is evaluated
+        auto locate = [&](int base, int &r, int &c) {
             const int idx = base + lane;
-            bool valid = idx < total;
+            if (idx >= total) return false;
+            int rem;
+            const int q = div_exact(idx, wc, inv_wc, rem);
+            r = rmin + q; c = cmin + rem;
+            return true;
+        };
+        int nr = 0, nc = 0;
+        bool nvalid = locate(0, nr, nc);
+        GradTaps ntaps = {};
+        if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);
+        for (int base = 0; base < total; base += 64) {
+            bool valid = nvalid;
+            const int r = nr, c = nc;
+            const GradTaps taps = ntaps;
+            nvalid = locate(base + 64, nr, nc);
+            if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);
             int bin = -1;
             float val = 0.0f;
             if (valid) {
-                int rem;
-                const int q = div_exact(idx, wc, inv_wc, rem);
-                const int r = rmin + q, c = cmin + rem;
                 float gval, a;
-                gradient_at(I, c, r, W, H, gval, a);
+                gradient_eval(taps, gval, a);
                 float dif = (float)r - k.y;
                 float distsq = dif * dif;
                 dif = (float)c - k.z;
@@ -148,13 +177,23 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                     val = siftmath::expf_(-distsq / two_s2) * gval;
                 }
             }
-            uint64_t mask = __ballot(valid);
-            while (mask) {               // raster order == ascending lane
-                const int l = __ffsll((unsigned long long)mask) - 1;
-                mask &= mask - 1;
-                const int sb = __builtin_amdgcn_readlane(bin, l);
-                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), l));
-                if (lane == sb) h = h + sv;
+            // Ordered accumulation.  The reference adds the samples into hist[bin] in raster order = ascending lane
+            // here.  Lane b collects the 64-bit mask of the lanes that vote for bin b (36 ballots), then every owner
+            // walks ITS mask in ascending order, fetching each value with a lane-indexed read (ds_bpermute): the trip
+            // count is the largest number of votes for one bin, not the number of samples in the batch.
+            uint32_t mlo = 0u, mhi = 0u;
+            const int vbin = valid ? bin : -1;
+#pragma unroll
+            for (int b = 0; b < 36; b++) {
+                const uint64_t m = __ballot(vbin == b);
+                if (lane == b) { mlo = (uint32_t)m; mhi = (uint32_t)(m >> 32); }
+            }
+            uint64_t mine = (uint64_t)mlo | ((uint64_t)mhi << 32);
+            while (__ballot(mine != 0)) {
+                const int l = mine ? (__ffsll((unsigned long long)mine) - 1) : lane;
+                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l << 2, __builtin_bit_cast(int, val)));
+                if (mine) h = h + sv;
+                mine &= mine - 1;
             }
         }
         // six passes of circular [1 1 1]/3 smoothing; hist[35] sees the already updated hist[0];

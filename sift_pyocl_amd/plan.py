@@ -309,6 +309,23 @@ class SiftPlan(object):
         out.update(blur0_ms=blur.value, blur0_launches=nl.value, blur0_pixels=px.value)
         return out
 
+    def count_kp(self, output):
+        """Print the number of keypoint per octave (plan.py:811-821): `output` = one (n, 4) array per octave,
+        rows with column 1 == -1 are holes"""
+        kpt = 0
+        for octave, data in enumerate(output):
+            if len(output) > 0:
+                ksum = int((numpy.asarray(data)[:, 1] != -1.0).sum())
+                kpt += ksum
+                print("octave %i kp count %i/%i size %s ratio:%s" % (octave, ksum, self.kpsize, self.scales[octave],
+                                                                    1000.0 * ksum / self.scales[octave][1] / self.scales[octave][0]))
+        print("Found total %i guess %s pixels per keypoint" % (kpt, self.shape[0] * self.shape[1] / max(kpt, 1)))
+
+    def debug_holes(self, label=""):
+        """plan.py:823-824 prints the holes of the keypoint buffer; the lists of this build are appended through a device
+        counter and have none."""
+        print("%s %s" % (label, numpy.empty(0, dtype=numpy.int64)))
+
     def log_profile(self):
         """If profiling is on, print the device time of every stage of the last call."""
         t = orient = descr = 0.0
@@ -328,3 +345,16 @@ class SiftPlan(object):
     def reset_timer(self):
         with self._sem:
             self.events = []
+
+
+def demo():
+    """plan.py:857-866 (scipy's sample image needs a download: a synthetic frame is used instead)"""
+    rng = numpy.random.default_rng(0)
+    from scipy.ndimage import gaussian_filter
+    img = gaussian_filter(rng.random((512, 512)), 2.0).astype(numpy.float32)
+    s = SiftPlan(template=img)
+    print(s.keypoints(img))
+
+
+if __name__ == "__main__":
+    demo()

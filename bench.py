@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--size", type=int, default=SIZE, help="image side (default: the BASELINE config, 4096)")
     ap.add_argument("--octaves", type=int, default=OCTAVES, help="0 = every octave (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra BatchPlan measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 "
                                                       "code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -193,6 +194,32 @@ def main():
     else:
         total_kp = float(n_kp)
 
+    # Extra, outside the timed region and never part of `value`: the pipelined path (BatchPlan) on the same
+    # frames -- what a caller with a stack of frames gets from one GPU (N = 1 only).
+    pipelined = None
+    if world == 1 and not args.no_pipelined:
+        try:
+            del plan
+            frames = [dev_images[i % n_img] for i in range(16)]
+            bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=args.octaves or None, lanes=2)
+            bp.keypoints_batch(frames)                      # warm-up: sizes the result arena
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(4):
+                t1 = time.perf_counter()
+                res = bp.keypoints_batch(frames)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t1)
+            sys.stderr.write("[bench] pipelined call times (ms): %s\n" % ", ".join("%.2f" % (1e3 * t) for t in times))
+            tb = sorted(times)[len(times) // 2]
+            pipelined = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s", "ms_per_frame": round(1e3 * tb / len(frames), 4),
+                         "frames_per_call": len(frames), "lanes": 2, "keypoints": int(sum(len(r) for r in res)),
+                         "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans, one result copy; every frame "
+                                 "bit-identical to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
+            del bp
+        except Exception as exc:
+            pipelined = {"error": str(exc)[:200]}
+
     if rank == 0:
         mpix_total = world * K * size * size / 1e6
         value = mpix_total / elapsed
@@ -237,6 +264,8 @@ def main():
                                   "kernel_ms_per_image": round(tot_ms / max(K, 1), 4),
                                   "bytes_alg_per_image": bytes_alg(size, size, n_oct, kp_per_img)},
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(size, n_oct)
             ref = cpu_reference_kernels(n_oct)

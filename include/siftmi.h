@@ -136,6 +136,12 @@ int siftmi_batch_set_params(siftmi_batch *batch, const siftmi_params *params);
 int siftmi_batch_info(const siftmi_batch *batch, int32_t *lanes, int64_t *bytes_allocated);
 int siftmi_batch_keypoints(siftmi_batch *batch, const void *const *images, int32_t n_images, int32_t image_dtype,
                            int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow);
+/* same, delivering records into caller-owned host arrays while the batch runs: frame i goes to host_outs[i] if its
+ * count fits host_caps[i] (offsets[i] = -1), otherwise it stays parked on the device at offsets[i] for siftmi_batch_fetch;
+ * *total_parked = records parked.  The blocking per-frame copy overlaps the other lanes' kernels. */
+int siftmi_batch_keypoints_into(siftmi_batch *batch, const void *const *images, int32_t n_images, int32_t image_dtype,
+                                int32_t images_are_device, siftmi_keypoint *const *host_outs, const int64_t *host_caps,
+                                int64_t *counts, int64_t *offsets, int64_t *total_parked, int32_t *overflow);
 int siftmi_batch_fetch(siftmi_batch *batch, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count);
 
 /* ---- MatchPlan -----------------------------------------------------------------------------

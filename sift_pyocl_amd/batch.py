@@ -30,6 +30,7 @@ class BatchPlan(SiftPlan):
 
     def __init__(self, *args, **kwargs):
         self.lanes = int(kwargs.pop("lanes", 4))
+        self._records_per_frame = 4096.0
         if kwargs.get("profile"):
             raise RuntimeError("BatchPlan does not collect per-stage events; profile a SiftPlan instead")
         SiftPlan.__init__(self, *args, **kwargs)
@@ -91,18 +92,40 @@ class BatchPlan(SiftPlan):
                 raise RuntimeError("the frames of a batch must be all host arrays or all device tensors")
             counts = (C.c_int64 * n)()
             offsets = (C.c_int64 * n)()
-            total = C.c_int64(0)
+            parked = C.c_int64(0)
             ovf = C.c_int32(0)
-            _lib.check(L.siftmi_batch_keypoints(self._handle, ptrs, n, code, dev_flags.pop(), counts, offsets, C.byref(total),
-                                                C.byref(ovf)))
+            # Records are delivered frame by frame into host arrays while the batch runs.  Their capacity is a guess (1.5x
+            # the records per frame of the previous batch); a frame that does not fit stays parked on the device and is
+            # fetched afterwards.  Many lanes of small frames: the host must keep feeding the lanes, so everything is
+            # parked and fetched with one copy at the end instead.
+            direct = self.lanes <= 2
+            outs = (C.c_void_p * n)()
+            caps = (C.c_int64 * n)()
+            arrays = [None] * n
+            if direct:
+                cap = int(1.5 * self._records_per_frame) + 256
+                for i in range(n):
+                    arrays[i] = numpy.empty(cap, dtype=self.dtype_kp)
+                    outs[i] = arrays[i].ctypes.data
+                    caps[i] = cap
+            _lib.check(L.siftmi_batch_keypoints_into(self._handle, ptrs, n, code, dev_flags.pop(), outs if direct else None,
+                                                     caps if direct else None, counts, offsets, C.byref(parked), C.byref(ovf)))
             self.overflow = bool(ovf.value)
             if self.overflow:
                 logger.warning("Keypoint counter overflow: more than %s keypoints in a frame, result truncated", self.kpsize)
-            flat = numpy.empty(total.value, dtype=self.dtype_kp)
-            if total.value:
-                _lib.check(L.siftmi_batch_fetch(self._handle, flat.ctypes.data, 0, 0, total.value))
+            flat = None
+            if parked.value:
+                flat = numpy.empty(parked.value, dtype=self.dtype_kp)
+                _lib.check(L.siftmi_batch_fetch(self._handle, flat.ctypes.data, 0, 0, parked.value))
+            result = []
+            for i in range(n):
+                if offsets[i] < 0:
+                    result.append(arrays[i][:counts[i]].view(numpy.recarray))
+                else:
+                    result.append(flat[offsets[i]:offsets[i] + counts[i]].view(numpy.recarray))
+            self._records_per_frame = max(1.0, sum(counts) / float(n))
             del keep
-        return [flat[offsets[i]:offsets[i] + counts[i]].view(numpy.recarray) for i in range(n)]
+        return result
 
     def keypoints(self, image):
         return self.keypoints_batch([image])[0]

@@ -407,6 +407,8 @@ int siftmi_device_name(int device_id, char *buf, int64_t buflen) {
     return SIFTMI_OK;
 }
 
+static thread_local bool g_creating_lane = false;   // set by siftmi_batch_create around its plan constructions
+
 int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id,
                        const siftmi_params *params, int32_t profile, siftmi_plan **out) {
     if (!out || !params) return fail(SIFTMI_EINVAL, "null argument");
@@ -440,7 +442,8 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     int rc = SIFTMI_OK;
     // The pyramid stream and the later-octave stream get a higher priority than the octave-0 detection stream, whose
     // long orientation / descriptor kernels would otherwise win every dispatch slot (measured: -1 % per image).
-    static const bool prio = getenv("SIFTMI_NO_PRIO") == nullptr;
+    static const bool prio_env = getenv("SIFTMI_NO_PRIO") == nullptr;
+    const bool prio = prio_env && !g_creating_lane;     // single-stream lanes of a batch are peers: no priorities between them
     int prio_lo = 0, prio_hi = 0;
     if (prio) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hipError_t e = prio ? hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
@@ -769,6 +772,8 @@ struct siftmi_batch {
     size_t arena_cap = 0, arena_used = 0;
     std::vector<int64_t> counts, offsets;
     int64_t retired = 0, batch_size = 0;  // frames retired so far / frames in the current batch
+    siftmi_keypoint *const *host_outs = nullptr;   // optional: one caller-owned host array per frame, filled while the batch runs
+    const int64_t *host_caps = nullptr;            // their capacities in records (a frame that does not fit stays parked in the arena)
 };
 extern "C" {
 
@@ -791,11 +796,16 @@ int siftmi_batch_create(int32_t height, int32_t width, int32_t in_dtype, int32_t
     b->device = device_id;
     for (int l = 0; l < lanes; l++) {
         siftmi_plan *p = nullptr;
+        // Small frames with many lanes: one stream per lane, all at the same priority.  Lanes already overlap each other,
+        // and three streams per lane oversubscribe the hardware queues (512^2, 8 lanes: 0.70 ms per frame with three
+        // streams, 0.43 ms with one; priorities between peer lanes cost another 20 %).  Few lanes of large frames keep the
+        // three prioritised streams of a plain plan (4096^2, 2 lanes: 1.05 ms per frame with, 1.40 ms without priorities).
+        const bool single_stream = lanes >= 4 && (int64_t)height * width <= (int64_t)2048 * 2048;
+        g_creating_lane = single_stream;
         int rc = siftmi_plan_create(height, width, in_dtype, device_id, params, 0, &p);
+        g_creating_lane = false;
         if (rc) { std::string keep = g_err; siftmi_batch_destroy(b); g_err = keep; return rc; }
-        // Small frames with many lanes: one stream per lane.  Lanes already overlap each other, and three streams per
-        // lane oversubscribe the hardware queues (512^2, 8 lanes: 0.70 ms per frame with three streams, 0.43 ms with one).
-        if (lanes >= 4 && (int64_t)height * width <= (int64_t)2048 * 2048) p->overlap = false;
+        if (single_stream) p->overlap = false;
         b->lanes.push_back(p);
         b->lane_image.push_back(-1);
     }
@@ -831,7 +841,21 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     int rc = plan_wait(p, &n, &ovf);
     if (rc) return rc;
     if (ovf && overflow) *overflow = 1;
-    const size_t need = b->arena_used + (size_t)n * sizeof(KpRecord);
+    const size_t bytes = (size_t)n * sizeof(KpRecord);
+    if (b->host_outs && b->host_outs[img] && n <= b->host_caps[img]) {
+        // straight into the caller's array for this frame: a blocking copy of one frame's records (~1.5 MB) costs the
+        // host ~0.1 ms while the other lanes keep the GPU busy -- cheaper than parking everything and copying it at the end
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(b->host_outs[img], p->records, bytes, hipMemcpyDeviceToHost, p->fin));
+            HIPCHK(hipStreamSynchronize(p->fin));
+        }
+        b->counts[(size_t)img] = n;
+        b->offsets[(size_t)img] = -1;                 // delivered
+        b->retired++;
+        b->lane_image[l] = -1;
+        return SIFTMI_OK;
+    }
+    const size_t need = b->arena_used + bytes;
     if (need > b->arena_cap) {
         // grow to the projected size of the whole batch (records so far / frames retired x frames of the batch,
         // +25 %), so that a batch regrows the arena at most a couple of times: each regrow drains the device
@@ -849,7 +873,7 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
         b->arena = bigger; b->arena_cap = cap;
     }
     if (n > 0)
-        HIPCHK(hipMemcpyAsync(b->arena + b->arena_used, p->records, (size_t)n * sizeof(KpRecord), hipMemcpyDeviceToDevice, p->fin));
+        HIPCHK(hipMemcpyAsync(b->arena + b->arena_used, p->records, bytes, hipMemcpyDeviceToDevice, p->fin));
     b->counts[(size_t)img] = n;
     b->offsets[(size_t)img] = (int64_t)(b->arena_used / sizeof(KpRecord));
     b->arena_used = need;
@@ -860,33 +884,43 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
 }  // namespace
 extern "C" {
 
-int siftmi_batch_keypoints(siftmi_batch *b, const void *const *images, int32_t n_images, int32_t image_dtype,
-                           int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow) {
-    if (!b || (n_images > 0 && !images) || !counts || !offsets || !total) return fail(SIFTMI_EINVAL, "null argument");
+int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int32_t n_images, int32_t image_dtype,
+                                int32_t images_are_device, siftmi_keypoint *const *host_outs, const int64_t *host_caps,
+                                int64_t *counts, int64_t *offsets, int64_t *total_parked, int32_t *overflow) {
+    if (!b || (n_images > 0 && !images) || !counts || !offsets || !total_parked) return fail(SIFTMI_EINVAL, "null argument");
     if (n_images < 0) return fail(SIFTMI_EINVAL, "negative image count");
+    if ((host_outs == nullptr) != (host_caps == nullptr)) return fail(SIFTMI_EINVAL, "host_outs and host_caps go together");
     HIPCHK(hipSetDevice(b->device));
     if (overflow) *overflow = 0;
-    *total = 0;
+    *total_parked = 0;
     b->arena_used = 0;
     b->retired = 0; b->batch_size = n_images;
+    b->host_outs = host_outs; b->host_caps = host_caps;
     b->counts.assign((size_t)n_images, 0);
     b->offsets.assign((size_t)n_images, 0);
     if (images_are_device) HIPCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams
     const size_t L = b->lanes.size();
-    int rc;
-    for (int i = 0; i < n_images; i++) {
-        if (!images[i]) return fail(SIFTMI_EINVAL, "null image %d", i);
+    int rc = SIFTMI_OK;
+    for (int i = 0; i < n_images && !rc; i++) {
+        if (!images[i]) { rc = fail(SIFTMI_EINVAL, "null image %d", i); break; }
         const size_t l = (size_t)i % L;
-        if ((rc = batch_retire(b, l, overflow))) return rc;
-        if ((rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false))) return rc;
+        if ((rc = batch_retire(b, l, overflow))) break;
+        if ((rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false))) break;
         b->lane_image[l] = i;
     }
-    for (size_t l = 0; l < L; l++)
-        if ((rc = batch_retire(b, l, overflow))) return rc;
+    for (int i = n_images > (int)L ? n_images - (int)L : 0; i < n_images && !rc; i++) rc = batch_retire(b, (size_t)i % L, overflow);
+    b->host_outs = nullptr; b->host_caps = nullptr;
+    if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());                            // the parking copies
     for (int i = 0; i < n_images; i++) { counts[i] = b->counts[(size_t)i]; offsets[i] = b->offsets[(size_t)i]; }
-    *total = (int64_t)(b->arena_used / sizeof(KpRecord));
+    *total_parked = (int64_t)(b->arena_used / sizeof(KpRecord));
     return SIFTMI_OK;
+}
+
+int siftmi_batch_keypoints(siftmi_batch *b, const void *const *images, int32_t n_images, int32_t image_dtype,
+                           int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow) {
+    return siftmi_batch_keypoints_into(b, images, n_images, image_dtype, images_are_device, nullptr, nullptr, counts, offsets, total,
+                                       overflow);
 }
 
 int siftmi_batch_fetch(siftmi_batch *b, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count) {

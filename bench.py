@@ -12,7 +12,7 @@ exchange step of the batched path, an RCCL all-gather of the keypoint records of
 Rank 0 prints ONE JSON line.
 
 roofline: the dominant kernel family is the fused separable Gaussian blur (blur_march_kernel<N,NORM>,
-16 launches per image, 38.8 % of the GPU time in profiles/r01/rocprofv3_summary.txt).  Its algorithmic traffic is
+16 launches per image, 42.7 % of the GPU time in profiles/r01/rocprofv3_summary.txt).  Its algorithmic traffic is
 1 read + 1 write of the plane = 8 B per pixel per launch ("5 chained blurs: 5R + 5W"); achieved =
 6 * 8 * W*H / (hipEvent time around the six full-resolution launches of an image: initial blur + the five scales
 of octave 0), measured live with HIP events on the plan's own pyramid stream; those launches run alone on the GPU,

@@ -210,11 +210,36 @@ void launch_march_nt(hipStream_t st, const void *in, float *out, int W, int H, c
     hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT, DT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
 }
 
-template <int N, bool NORM>
-void launch_march_t(hipStream_t st, const float *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
-    static const int nt = getenv("SIFTMI_MARCH_NT") ? atoi(getenv("SIFTMI_MARCH_NT")) : 128;   // dev knob: 64 = one wave per workgroup
-    if (nt == 64) launch_march_nt<N, NORM, 64>(st, (const void *)in, out, W, H, taps, mm);
-    else launch_march_nt<N, NORM, 128>(st, (const void *)in, out, W, H, taps, mm);
+// team form of the marching blur (blur_team_kernel): S sub-blocks per accumulator period, `wgs` workgroups wanted
+template <int N, bool NORM, int S, int DT = 0>
+void launch_team(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs) {
+    using G = March2Geom<N, 128, S>;
+    TapsArg<N> ta;
+    for (int i = 0; i < N; i++) ta.t[i] = taps[i];
+    const int gx = (W + G::TX - 1) / G::TX;
+    const int want_segments = (wgs + gx - 1) / gx;
+    const int rows = (H + want_segments - 1) / want_segments;
+    int nblocks = (rows + (N - 1) + N - 1) / N;
+    if (nblocks < 3) nblocks = 3;
+    const int rows_out = nblocks * N - (N - 1);
+    dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
+    hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+}
+
+// Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
+// plane (tools/ubench/blur_team.hip: 31 / 38 / 41 / 47 / 65 us against 33 / 43 / 45 / 53 / 73 us for the one-block form);
+// SIFTMI_NO_TEAM=1 (dev knob) falls back to the one-block marching kernel.
+template <int N, bool NORM, int DT = 0>
+void launch_march_t(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+    static const bool no_team = getenv("SIFTMI_NO_TEAM") != nullptr;
+    if (no_team) {
+        static const int nt = getenv("SIFTMI_MARCH_NT") ? atoi(getenv("SIFTMI_MARCH_NT")) : 128;   // dev knob: 64 = one wave per workgroup
+        if (nt == 64) launch_march_nt<N, NORM, 64, DT>(st, in, out, W, H, taps, mm);
+        else launch_march_nt<N, NORM, 128, DT>(st, in, out, W, H, taps, mm);
+        return;
+    }
+    constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
+    launch_team<N, NORM, S, DT>(st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024);
 }
 
 // returns false when no tiled instantiation exists for this tap count
@@ -267,7 +292,7 @@ template <int DT>
 bool launch_init_blur_dt(hipStream_t st, const void *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
     if (t.n != 15) return false;
     if (W >= 1024 && H >= 512 && taps_symmetric(t) && !getenv("SIFTMI_NO_MARCH"))
-        launch_march_nt<15, true, 128, DT>(st, in, out, W, H, t.t, mm);
+        launch_march_t<15, true, DT>(st, in, out, W, H, t.t, mm);
     else
         launch_blur_t<15, true, DT>(st, in, out, W, H, t.t, mm);
     return true;

@@ -16,7 +16,7 @@ namespace siftk {
 // 4-5 waves share a SIMD instead of 2.5: with the one-block form the load/stage/H/V phases of the few resident
 // waves line up and the memory skeleton (32 us at 27 taps, 4096^2) and the arithmetic (41 us) add instead of
 // overlapping (tools/ubench/blur_abl.hip).
-template <int N, int S> struct SubSplit {
+template <int N, int S> struct XSubSplit {
     static constexpr int RB = (((N + S - 1) / S) + 1) & ~1;
     static constexpr int rows(int s) { return (N - s * RB) < RB ? (N - s * RB) : RB; }
     static constexpr int pairs(int s) { return (rows(s) + 1) / 2; }
@@ -24,8 +24,8 @@ template <int N, int S> struct SubSplit {
     static_assert(N - (S - 1) * RB > 0, "empty last sub-block");
 };
 
-template <int N, int NT, int S> struct March2Geom {
-    using SS = SubSplit<N, S>;
+template <int N, int NT, int S> struct XMarch2Geom {
+    using SS = XSubSplit<N, S>;
     static constexpr int TX = 2 * NT;
     static constexpr int C = (N & 1) ? N / 2 : N / 2 - 1;
     static constexpr int NPS = SS::NPS;
@@ -41,8 +41,8 @@ template <int N, bool NORM, int NT, int S, int DT = 0>
 __global__ __launch_bounds__(NT) void blur_march2_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                          int W, int H, int nblocks, TapsArg<N> taps,
                                                          const uint32_t *__restrict__ mm) {
-    using G = March2Geom<N, NT, S>;
-    using SS = SubSplit<N, S>;
+    using G = XMarch2Geom<N, NT, S>;
+    using SS = XSubSplit<N, S>;
     static_assert(N & 1, "marching blur needs an odd tap count");
     extern __shared__ float4 smem4[];
     float *s = reinterpret_cast<float *>(smem4);
@@ -235,7 +235,7 @@ template <class F> float timeit(F f) {
 template <int N, int S> void run(const float *in, float *o1, float *o2, int W, int H, const float *taps) {
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
-    using G1 = MarchGeom<N, 128>; using G2 = March2Geom<N, 128, S>;
+    using G1 = MarchGeom<N, 128>; using G2 = XMarch2Geom<N, 128, S>;
     const int nb = nblocks_for<N>(W, H, G1::TX);
     const int rows_out = nb * N - (N - 1);
     dim3 grid((unsigned)((W + G1::TX - 1) / G1::TX), (unsigned)((H + rows_out - 1) / rows_out));

@@ -557,8 +557,8 @@ template <int N, int NT, int S> struct March2Geom {
 // Step g = (block, sub-block): the H team filters sub-block g horizontally in LDS buffer g % 3 while the V team
 // marches sub-block g-1 vertically out of buffer (g-1) % 3 (accumulators, global stores) and then stages sub-block
 // g+1 (prefetched registers -> buffer (g+1) % 3) and issues the loads of g+2.  One barrier per step.
-template <int N, bool NORM, int S, int DT = 0>
-__global__ __launch_bounds__(256) void blur_team_kernel(const void *__restrict__ in, float *__restrict__ out,
+template <int N, bool NORM, int S, int DT = 0, int HW = 2>
+__global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                           int W, int H, int nblocks, TapsArg<N> taps,
                                                           const uint32_t *__restrict__ mm) {
     constexpr int NT = 128;                       // threads per team
@@ -568,8 +568,9 @@ __global__ __launch_bounds__(256) void blur_team_kernel(const void *__restrict__
     constexpr int BUF = G::NPS * G::PITCH * 2;    // floats per LDS buffer
     extern __shared__ float4 smem4[];
     float *sbase = reinterpret_cast<float *>(smem4);
-    const int role = threadIdx.x >> 7;            // 0: H team, 1: V team (wave-uniform)
-    const int tid = threadIdx.x & 127;
+    // HW waves form the H team (threads 0 .. 64*HW-1), the last two waves the V team
+    const int role = threadIdx.x >= 64 * HW ? 1 : 0;            // wave-uniform
+    const int tid = role ? (int)threadIdx.x - 64 * HW : (int)threadIdx.x;
     const int x0 = blockIdx.x * G::TX;
     const int rows_out = nblocks * N - (N - 1);
     const int ys = blockIdx.y * rows_out;
@@ -645,9 +646,9 @@ __global__ __launch_bounds__(256) void blur_team_kernel(const void *__restrict__
         for (int u = 0; u < G::NB; u++)
             if (hb_rp[u] < np) *reinterpret_cast<f32x2 *>(s + (hb_rp[u] * G::PITCH + hb_col[u]) * 2) = norm2(ph[u]);
     };
-    // horizontal pass of one sub-block (np row pairs) in place, by the 128 threads of the H team
+    // horizontal pass of one sub-block (np row pairs) in place, by the HW waves of the H team (one wave per row pair)
     auto hpass = [&](float *s, int np) {
-        for (int task = tid; task < np * (NT / 2); task += NT) {
+        for (int task = tid; task < np * (NT / 2); task += 64 * HW) {
             const int rp = task / (NT / 2), t4 = task % (NT / 2);
             float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
             f32x2 w[G::NW];

@@ -2,7 +2,7 @@
 # dev: kernel trace of a few bench steps; prints the timeline of the last image (start/end relative to its first kernel)
 R=$(pwd); OUT=$R/gpurun_out/trace_gaps; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $OUT -o kt --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/err.txt
+rocprofv3 --kernel-trace -d $OUT -o kt --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pipelined > /dev/null 2> $OUT/err.txt
 cd $R
 python - <<'PY'
 import csv, glob

@@ -25,7 +25,7 @@ template <class F> float timeit(F f) {
     }
     return best * 1e3f;
 }
-template <int N, int S> void run(const float *in, float *o1, float *o2, int W, int H, const float *taps) {
+template <int N, int S, int HW = 2> void run(const float *in, float *o1, float *o2, int W, int H, const float *taps) {
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     using G1 = MarchGeom<N, 128>; using G2 = March2Geom<N, 128, S>;
@@ -38,12 +38,12 @@ template <int N, int S> void run(const float *in, float *o1, float *o2, int W, i
     const size_t lds3 = (size_t)3 * G2::LDS_BYTES;
     hipMemset(o1, 0, (size_t)W * H * 4); hipMemset(o2, 0xff, (size_t)W * H * 4);
     float t1 = timeit([&] { hipLaunchKernelGGL((blur_march_kernel<N, false, 128, 0>), grid, dim3(128), (size_t)G1::LDS_BYTES, 0, (const void *)in, o1, W, H, nb, ta, (const uint32_t *)nullptr); });
-    float t2 = timeit([&] { hipLaunchKernelGGL((blur_team_kernel<N, false, S, 0>), grid2, dim3(256), lds3, 0, (const void *)in, o2, W, H, nb2, ta, (const uint32_t *)nullptr); });
+    float t2 = timeit([&] { hipLaunchKernelGGL((blur_team_kernel<N, false, S, 0, HW>), grid2, dim3(64 * HW + 128), lds3, 0, (const void *)in, o2, W, H, nb2, ta, (const uint32_t *)nullptr); });
     std::vector<float> a((size_t)W * H), b((size_t)W * H);
     hipMemcpy(a.data(), o1, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o2, b.size() * 4, hipMemcpyDeviceToHost);
     const bool same = memcmp(a.data(), b.data(), a.size() * 4) == 0;
     size_t bad = 0; for (size_t i = 0; i < a.size() && !same; i++) bad += memcmp(&a[i], &b[i], 4) != 0;
-    printf("N %2d S %d  %dx%d  product: grid %ux%u nb %d %.1f us | teams: grid %ux%u nb %d LDS %zu B %.1f us  %s (%zu differ)\n", N, S, W, H, grid.x, grid.y, nb, t1,
+    printf("N %2d S %d HW %d  %dx%d  product: grid %ux%u nb %d %.1f us | teams: grid %ux%u nb %d LDS %zu B %.1f us  %s (%zu differ)\n", N, S, HW, W, H, grid.x, grid.y, nb, t1,
            grid2.x, grid2.y, nb2, lds3, t2, same ? "BITWISE EQUAL" : "MISMATCH", bad);
 }
 int main(int argc, char **argv) {
@@ -63,5 +63,7 @@ int main(int argc, char **argv) {
     mk(17); run<17, 3>(in, o1, o2, W, H, taps);
     mk(21); run<21, 3>(in, o1, o2, W, H, taps);
     mk(27); run<27, 3>(in, o1, o2, W, H, taps); run<27, 4>(in, o1, o2, W, H, taps);
+    mk(15); run<15, 2, 3>(in, o1, o2, W, H, taps); mk(17); run<17, 3, 3>(in, o1, o2, W, H, taps); mk(21); run<21, 3, 3>(in, o1, o2, W, H, taps);
+    mk(27); run<27, 4, 3>(in, o1, o2, W, H, taps); run<27, 4, 4>(in, o1, o2, W, H, taps); mk(21); run<21, 3, 4>(in, o1, o2, W, H, taps);
     return 0;
 }

@@ -118,6 +118,7 @@ struct siftmi_plan {
     void *raw = nullptr;          // host-input staging (any dtype)
     int raw_dtype = -1;           // dtype of the image currently staged in `raw` (-1: none)
     hipStream_t fin = nullptr;    // stream on which the last enqueued image ends
+    int last_group0 = 0;          // oriented keypoints of octave 0 in the previous image (occupancy heuristic)
     hipEvent_t ev_join = nullptr;
     struct HostBack { Counters c; } *hb = nullptr;   // pinned read-back block (one async D->H + one wait per image)
     void *warp_in = nullptr, *warp_out = nullptr;   // siftmi_plan_transform staging, grown on demand
@@ -397,7 +398,14 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         snprintf(lab, sizeof lab, "descriptors group %d", group);
         Scope sc(p, lab, false, 0, st);
         static const int desc_blocks = getenv("SIFTMI_DESC_BLOCKS") ? atoi(getenv("SIFTMI_DESC_BLOCKS")) : 2048;   // dev knob
-        static const int desc_pad = getenv("SIFTMI_DESC_PAD") ? atoi(getenv("SIFTMI_DESC_PAD")) : 0;   // dev knob: extra LDS per block
+        // Residency throttle.  With few keypoints (a white-noise 4096^2 frame has ~8 k in octave 0) the descriptor kernel is
+        // not the bottleneck, but at full occupancy (5 waves per SIMD x 96 VGPRs) it leaves no registers for the
+        // later octaves' blur / detection kernels, whose chain then trails it by > 100 us.  20 KB of unused dynamic LDS
+        // cap it at 3 blocks per CU; the later-octave kernels slip in (-4 % per image).  Keypoint-dense frames
+        // (> 20 k in octave 0, judged by the previous frame of this plan) are descriptor-bound and run unthrottled (+12 %).
+        static const int desc_pad_env = getenv("SIFTMI_DESC_PAD") ? atoi(getenv("SIFTMI_DESC_PAD")) : -1;   // dev knob
+        int desc_pad = (group == 0 && p->overlap && p->n_oct > 1 && p->last_group0 <= 20000) ? 20000 : 0;
+        if (desc_pad_env >= 0) desc_pad = desc_pad_env;
         hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                            (const float4 *)p->okp, (const int *)p->oaux, p->cnt, group, 0, 0, kcap, p->records);
     }
@@ -738,6 +746,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     int ovf = hc.overflow;
     if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
     p->last_count = n;
+    p->last_group0 = hc.grp_out_end[0] - hc.grp_out_start[0];
     *n_out = n;
     if (overflow) *overflow = ovf;
     return SIFTMI_OK;

@@ -154,6 +154,7 @@ class SiftPlan(object):
         self._par_key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
         self._create(L)
         self.overflow = False
+        self._last_n = 0
         self.debug = []
 
     def _create(self, L):
@@ -258,14 +259,25 @@ class SiftPlan(object):
                 self._params, self._par_key = params, key
             n = C.c_int64(0)
             ovf = C.c_int32(0)
-            # count first (records stay on the device), then fetch straight into an exactly sized array
-            _lib.check(L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, None, 0, 0, C.byref(n), C.byref(ovf)))
+            # One call: the records land in an array sized from the previous frame's count (x1.5; untouched pages of
+            # numpy.empty cost nothing), so the host does not come back to Python between the count and the copy.  If the
+            # frame has more keypoints than guessed, the records are still on the device: fetch them into an exact array.
+            cap = int(1.5 * self._last_n) + 256
+            output = numpy.empty(cap, dtype=self.dtype_kp)
+            rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, output.ctypes.data, 0, cap, C.byref(n), C.byref(ovf))
+            _lib.check(rc, allow=(_lib.ECAPACITY,))
+            count = n.value
+            if rc == _lib.ECAPACITY:
+                total = C.c_int64(0)
+                _lib.check(L.siftmi_plan_records_device(self._handle, C.byref(C.c_void_p()), C.byref(total)))
+                count = total.value
+                output = numpy.empty(count, dtype=self.dtype_kp)
+                _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, count))
+            self._last_n = count
+            output = output[:count]
             self.overflow = bool(ovf.value)
             if self.overflow:
                 logger.warning("Keypoint counter overflow: more than %s keypoints, result truncated", self.kpsize)
-            output = numpy.empty(n.value, dtype=self.dtype_kp)
-            if n.value:
-                _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, n.value))
             output = output.view(numpy.recarray)
             del keep
             if logger.isEnabledFor(logging.INFO):

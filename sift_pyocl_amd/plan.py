@@ -263,16 +263,24 @@ class SiftPlan(object):
             # numpy.empty cost nothing), so the host does not come back to Python between the count and the copy.  If the
             # frame has more keypoints than guessed, the records are still on the device: fetch them into an exact array.
             cap = int(1.5 * self._last_n) + 256
-            output = numpy.empty(cap, dtype=self.dtype_kp)
-            rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, output.ctypes.data, 0, cap, C.byref(n), C.byref(ovf))
-            _lib.check(rc, allow=(_lib.ECAPACITY,))
-            count = n.value
-            if rc == _lib.ECAPACITY:
+            if cap * 144 <= (8 << 20):
+                output = numpy.empty(cap, dtype=self.dtype_kp)
+                rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, output.ctypes.data, 0, cap, C.byref(n), C.byref(ovf))
+                _lib.check(rc, allow=(_lib.ECAPACITY,))
+                count = n.value
+                exact = rc == _lib.ECAPACITY
+            else:
+                # large results: an over-sized array would be a fresh mmap (first-touch page faults on every call);
+                # count first, then copy into an exactly sized array that the allocator can recycle
+                _lib.check(L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, None, 0, 0, C.byref(n), C.byref(ovf)))
+                exact = True
+            if exact:
                 total = C.c_int64(0)
                 _lib.check(L.siftmi_plan_records_device(self._handle, C.byref(C.c_void_p()), C.byref(total)))
                 count = total.value
                 output = numpy.empty(count, dtype=self.dtype_kp)
-                _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, count))
+                if count:
+                    _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, count))
             self._last_n = count
             output = output[:count]
             self.overflow = bool(ovf.value)

@@ -22,7 +22,9 @@ struct BlurPlanes { const float *p[6]; };
 
 __device__ __forceinline__ float dog_at(const BlurPlanes &b, int s, size_t pos) { return b.p[s][pos] - b.p[s + 1][pos]; }
 
-__global__ __launch_bounds__(256) void extrema_kernel(BlurPlanes b, int W, int H, int border, double contrast,
+// 80 VGPRs (12 B of scratch) = 6 waves per SIMD instead of the natural 81 = 5: the kernel is latency bound (PMC: 70 % of
+// the wave time in s_waitcnt), 8 waves (64 VGPRs, 64 B of scratch) is twice as slow
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, double contrast,
                                                       float edth, float4 *__restrict__ cand,
                                                       int *__restrict__ counter, int capacity) {
     const int lane = threadIdx.x & 63;

@@ -120,7 +120,8 @@ struct siftmi_plan {
     hipStream_t fin = nullptr;    // stream on which the last enqueued image ends
     int last_group0 = 0;          // oriented keypoints of octave 0 in the previous image (occupancy heuristic)
     hipEvent_t ev_join = nullptr;
-    struct HostBack { Counters c; } *hb = nullptr;   // pinned read-back block (one async D->H + one wait per image)
+    struct HostBack { Counters c, c2; } *hb = nullptr;   // pinned read-back blocks (one asynchronous D->H per ending stream)
+    hipStream_t wait_a = nullptr, wait_b = nullptr;      // the stream(s) the image enqueued last ends on
     void *warp_in = nullptr, *warp_out = nullptr;   // siftmi_plan_transform staging, grown on demand
     size_t warp_in_bytes = 0, warp_out_bytes = 0;
     hipEvent_t ev_wa = nullptr, ev_wb = nullptr;
@@ -137,7 +138,7 @@ struct siftmi_plan {
     bool have_init = false;
     std::vector<Event> events;
     size_t n_events = 0;
-    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_last_b = nullptr;
     float last_min = 0, last_max = 0;
     int64_t last_count = 0;
     std::vector<void *> allocs;
@@ -440,7 +441,7 @@ int siftmi_device_name(int device_id, char *buf, int64_t buflen) {
     return SIFTMI_OK;
 }
 
-static thread_local bool g_creating_lane = false;   // set by siftmi_batch_create around its plan constructions
+static thread_local int g_lane_mode = 0;   // set by siftmi_batch_create around its plan constructions: 1 single-stream lane, 2 multi-stream lane
 
 int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id,
                        const siftmi_params *params, int32_t profile, siftmi_plan **out) {
@@ -473,10 +474,14 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     p->kpsize = (int64_t)(N / (size_t)params->pix_per_kp);   // plan.py:243
     if (p->kpsize < 1) p->kpsize = 1;
     int rc = SIFTMI_OK;
-    // The pyramid stream and the later-octave stream get a higher priority than the octave-0 detection stream, whose
-    // long orientation / descriptor kernels would otherwise win every dispatch slot (measured: -1 % per image).
-    static const bool prio_env = getenv("SIFTMI_NO_PRIO") == nullptr;
-    const bool prio = prio_env && !g_creating_lane;     // single-stream lanes of a batch are peers: no priorities between them
+    // Stream priorities (pyramid and later-octave streams above the octave-0 detection stream, whose long orientation /
+    // descriptor kernels would otherwise win every dispatch slot) pay off where two multi-stream plans share the GPU
+    // (BatchPlan with 2 lanes of large frames: 1.13 instead of 1.33 ms per 4096^2 frame); for a single plan they are
+    // within noise, and once a process has created prioritised streams its normal-priority streams get fewer hardware
+    // queues (8 single-stream lanes of 512^2 frames: 0.72 instead of 0.41 ms per frame).  Hence: only for the
+    // multi-stream lanes of a batch; SIFTMI_PRIO=1 forces them for plain plans (dev knob).
+    static const bool prio_env = getenv("SIFTMI_PRIO") != nullptr;
+    const bool prio = prio_env || g_lane_mode == 2;
     int prio_lo = 0, prio_hi = 0;
     if (prio) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hipError_t e = prio ? hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
@@ -511,7 +516,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc) rc = p->alloc(&p->records, (size_t)p->kpsize * sizeof(KpRecord));
     if (!rc) rc = compute_schedule(p);
     if (!rc && hipMemset(p->cnt, 0, sizeof(Counters)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipMemset failed");
-    if (!rc) { hipEventCreate(&p->ev_first); hipEventCreate(&p->ev_last); }
+    if (!rc) { hipEventCreate(&p->ev_first); hipEventCreate(&p->ev_last); hipEventCreate(&p->ev_last_b); }
     if (rc) { std::string keep = g_err; siftmi_plan_destroy(p); g_err = keep; return rc; }
     *out = p;
     return SIFTMI_OK;
@@ -536,6 +541,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     for (Event &e : p->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (p->ev_first) hipEventDestroy(p->ev_first);
     if (p->ev_last) hipEventDestroy(p->ev_last);
+    if (p->ev_last_b) hipEventDestroy(p->ev_last_b);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return SIFTMI_OK;
@@ -710,33 +716,45 @@ int enqueue_body(siftmi_plan *p) {
     // (Capturing this fork / join into a hipGraph was tried: it replays correctly -- as long as stream3 does not rejoin
     // through stream2, which crashes hipStreamEndCapture on ROCm 7.2 -- but a graph launch is no faster than the ~35 plain
     // launches: small images are bound by the GPU-side latency of dependent kernels, not by host launch cost.)
+    // The image ends on the two detection streams.  Each reads the counter block back into its own pinned copy right
+    // after its descriptor kernel (the host takes the copy with the larger record count: n_out only grows), instead of
+    // both rejoining the pyramid stream first: two cross-stream hops (~20 us) less on the critical path.
+    p->wait_a = p->stream; p->wait_b = nullptr;
     if (p->overlap && p->n_oct > 0) {
-        HIPCHK(hipEventRecord(p->ev_join, p->stream2));
-        HIPCHK(hipStreamWaitEvent(p->stream, p->ev_join, 0));
-        if (p->n_oct > 1) HIPCHK(hipStreamWaitEvent(p->stream, p->ev_grp1, 0));
+        if (p->profile) hipEventRecord(p->ev_last, p->stream2);
+        HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream2));
+        p->wait_a = p->stream2;
+        if (p->n_oct > 1) {
+            if (p->profile) hipEventRecord(p->ev_last_b, p->stream3);
+            HIPCHK(hipMemcpyAsync(&p->hb->c2, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream3));
+            p->wait_b = p->stream3;
+        }
+    } else {
+        if (p->profile) hipEventRecord(p->ev_last, p->stream);
+        HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream));
     }
-    hipStream_t fin = p->stream;
-    if (p->profile) hipEventRecord(p->ev_last, fin);
-    HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, fin));
-    p->fin = fin;
+    p->fin = p->stream;       // copies of the records are issued here after the wait: ordered before the next image's kernels
     return SIFTMI_OK;
 }
 
 // Wait for the image enqueued last on this plan; returns its record count (records stay on the device).
 int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     HIPCHK(hipSetDevice(p->device));
-    hipStream_t fin = p->fin ? p->fin : p->stream;
     // wait by polling: a blocking hipStreamSynchronize can add wake-up latency to a ~1 ms call
     static const bool spin = getenv("SIFTMI_NO_SPIN") == nullptr;
-    if (spin) {
-        hipError_t q;
-        while ((q = hipStreamQuery(fin)) == hipErrorNotReady) __builtin_ia32_pause();
-        if (q != hipSuccess) HIPCHK(q);
+    hipStream_t ws[2] = {p->wait_a ? p->wait_a : p->stream, p->wait_b};
+    for (hipStream_t w : ws) {
+        if (!w) continue;
+        if (spin) {
+            hipError_t q;
+            while ((q = hipStreamQuery(w)) == hipErrorNotReady) __builtin_ia32_pause();
+            if (q != hipSuccess) HIPCHK(q);
+        }
+        HIPCHK(hipStreamSynchronize(w));
     }
-    HIPCHK(hipStreamSynchronize(fin));
     HIPCHK(hipStreamSynchronize(p->stream));
-    const Counters &hc = p->hb->c;
-    const uint32_t *hmm = p->hb->c.mm;
+    const Counters &hc = (p->wait_b && p->hb->c2.n_out > p->hb->c.n_out) ? p->hb->c2 : p->hb->c;
+    const uint32_t *hmm = hc.mm;
     HIPCHK(hipGetLastError());
     {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
@@ -835,9 +853,9 @@ int siftmi_batch_create(int32_t height, int32_t width, int32_t in_dtype, int32_t
         // streams, 0.43 ms with one; priorities between peer lanes cost another 20 %).  Few lanes of large frames keep the
         // three prioritised streams of a plain plan (4096^2, 2 lanes: 1.05 ms per frame with, 1.40 ms without priorities).
         const bool single_stream = lanes >= 4 && (int64_t)height * width <= (int64_t)2048 * 2048;
-        g_creating_lane = single_stream;
+        g_lane_mode = single_stream ? 1 : 2;
         int rc = siftmi_plan_create(height, width, in_dtype, device_id, params, 0, &p);
-        g_creating_lane = false;
+        g_lane_mode = 0;
         if (rc) { std::string keep = g_err; siftmi_batch_destroy(b); g_err = keep; return rc; }
         if (single_stream) p->overlap = false;
         b->lanes.push_back(p);
@@ -1064,6 +1082,10 @@ int siftmi_plan_last_kernel_ms(const siftmi_plan *p, float *total_ms, float *blu
     if (!p->profile) return fail(SIFTMI_EINVAL, "plan was created with profile=0");
     float tot = 0;
     HIPCHK(hipEventElapsedTime(&tot, p->ev_first, p->ev_last));
+    if (p->wait_b) {
+        float tb = 0;
+        if (hipEventElapsedTime(&tb, p->ev_first, p->ev_last_b) == hipSuccess && tb > tot) tot = tb;
+    }
     if (total_ms) *total_ms = tot;
     return siftmi_plan_blur_ms(p, -1, blur_ms, blur_launches, blur_pixels);
 }

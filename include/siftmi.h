@@ -134,6 +134,10 @@ int siftmi_batch_create(int32_t height, int32_t width, int32_t in_dtype, int32_t
 int siftmi_batch_destroy(siftmi_batch *batch);
 int siftmi_batch_set_params(siftmi_batch *batch, const siftmi_params *params);
 int siftmi_batch_info(const siftmi_batch *batch, int32_t *lanes, int64_t *bytes_allocated);
+/* light profiling of the lanes (level 1: one hipEvent pair around the full-resolution blur launches of every frame, as
+ * siftmi_plan_create's profile = 1); siftmi_batch_blur_ms returns their sum over the frames of the last batch */
+int siftmi_batch_set_profile(siftmi_batch *batch, int32_t level);
+int siftmi_batch_blur_ms(const siftmi_batch *batch, double *blur_ms, int64_t *blur_launches, double *blur_pixels);
 int siftmi_batch_keypoints(siftmi_batch *batch, const void *const *images, int32_t n_images, int32_t image_dtype,
                            int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow);
 /* same, delivering records into caller-owned host arrays while the batch runs: frame i goes to host_outs[i] if its

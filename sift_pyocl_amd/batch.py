@@ -31,8 +31,10 @@ class BatchPlan(SiftPlan):
     def __init__(self, *args, **kwargs):
         self.lanes = int(kwargs.pop("lanes", 4))
         self._records_per_frame = 4096.0
-        if kwargs.get("profile"):
-            raise RuntimeError("BatchPlan does not collect per-stage events; profile a SiftPlan instead")
+        self._light = kwargs.get("profile") == "light"
+        if kwargs.get("profile") and not self._light:
+            raise RuntimeError("BatchPlan only supports profile='light' (blur brackets); profile a SiftPlan for per-stage events")
+        kwargs["profile"] = False
         SiftPlan.__init__(self, *args, **kwargs)
 
     def _create(self, L):
@@ -41,9 +43,17 @@ class BatchPlan(SiftPlan):
         nbytes = C.c_int64()
         _lib.check(L.siftmi_batch_info(self._handle, None, C.byref(nbytes)))
         self.memory = int(nbytes.value)
+        if self._light:
+            _lib.check(L.siftmi_batch_set_profile(self._handle, 1))
 
     def _destroy(self, L, h):
         L.siftmi_batch_destroy(h)
+
+    def blur_times(self):
+        """profile='light': hipEvent time, launches and pixels of the full-resolution blur launches of the last batch"""
+        ms = C.c_double(); nl = C.c_int64(); px = C.c_double()
+        _lib.check(_lib.lib().siftmi_batch_blur_ms(self._handle, C.byref(ms), C.byref(nl), C.byref(px)))
+        return {"blur0_ms": ms.value, "blur0_launches": nl.value, "blur0_pixels": px.value}
 
     def keypoints_batch(self, images):
         """Keypoints of a sequence of frames (all numpy / host, or all device tensors).

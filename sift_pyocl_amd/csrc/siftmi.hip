@@ -824,6 +824,8 @@ struct siftmi_batch {
     size_t arena_cap = 0, arena_used = 0;
     std::vector<int64_t> counts, offsets;
     int64_t retired = 0, batch_size = 0;  // frames retired so far / frames in the current batch
+    double blur0_ms = 0, blur0_pixels = 0;         // light profiling: octave-0 blur brackets summed over the frames of the batch
+    int64_t blur0_launches = 0;
     siftmi_keypoint *const *host_outs = nullptr;   // optional: one caller-owned host array per frame, filled while the batch runs
     const int64_t *host_caps = nullptr;            // their capacities in records (a frame that does not fit stays parked in the arena)
 };
@@ -871,6 +873,21 @@ int siftmi_batch_set_params(siftmi_batch *b, const siftmi_params *params) {
     return SIFTMI_OK;
 }
 
+int siftmi_batch_set_profile(siftmi_batch *b, int32_t level) {
+    if (!b) return fail(SIFTMI_EINVAL, "null batch");
+    if (level < 0 || level > 1) return fail(SIFTMI_EINVAL, "batch lanes support profile 0 or 1 (light)");
+    for (siftmi_plan *p : b->lanes) p->profile = level;
+    return SIFTMI_OK;
+}
+
+int siftmi_batch_blur_ms(const siftmi_batch *b, double *blur_ms, int64_t *blur_launches, double *blur_pixels) {
+    if (!b) return fail(SIFTMI_EINVAL, "null batch");
+    if (blur_ms) *blur_ms = b->blur0_ms;
+    if (blur_launches) *blur_launches = b->blur0_launches;
+    if (blur_pixels) *blur_pixels = b->blur0_pixels;
+    return SIFTMI_OK;
+}
+
 int siftmi_batch_info(const siftmi_batch *b, int32_t *lanes, int64_t *bytes_allocated) {
     if (!b) return fail(SIFTMI_EINVAL, "null batch");
     if (lanes) *lanes = (int32_t)b->lanes.size();
@@ -893,6 +910,10 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     int rc = plan_wait(p, &n, &ovf);
     if (rc) return rc;
     if (ovf && overflow) *overflow = 1;
+    if (p->profile) {
+        float ms = 0; int32_t nl = 0; double px = 0;
+        if (siftmi_plan_blur_ms(p, 0, &ms, &nl, &px) == SIFTMI_OK) { b->blur0_ms += ms; b->blur0_launches += nl; b->blur0_pixels += px; }
+    }
     const size_t bytes = (size_t)n * sizeof(KpRecord);
     if (b->host_outs && b->host_outs[img] && n <= b->host_caps[img]) {
         // straight into the caller's array for this frame: a blocking copy of one frame's records (~1.5 MB) costs the
@@ -947,6 +968,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     *total_parked = 0;
     b->arena_used = 0;
     b->retired = 0; b->batch_size = n_images;
+    b->blur0_ms = 0; b->blur0_pixels = 0; b->blur0_launches = 0;
     b->host_outs = host_outs; b->host_caps = host_caps;
     b->counts.assign((size_t)n_images, 0);
     b->offsets.assign((size_t)n_images, 0);

@@ -24,12 +24,18 @@ class BatchPlan(SiftPlan):
 
     ``lanes`` independent device plans take the frames round-robin; nothing waits on the host until a lane is
     reused, the records of the whole batch are parked on the device and come back in one copy
-    (``siftmi_batch_*`` in include/siftmi.h).  Same constructor keywords as ``SiftPlan`` plus ``lanes``;
+    (``siftmi_batch_*`` in include/siftmi.h).  Same constructor keywords as ``SiftPlan`` plus ``lanes`` (default: 8 for frames up to 2048 x 2048, else 2);
     ``keypoints_batch(images)`` returns one recarray per frame, each bit-identical to ``SiftPlan.keypoints``.
     """
 
     def __init__(self, *args, **kwargs):
-        self.lanes = int(kwargs.pop("lanes", 4))
+        lanes = kwargs.pop("lanes", None)
+        if lanes is None:
+            # measured on MI355X: many one-stream lanes for small frames (dependent-launch latency), two three-stream lanes
+            # for large ones (one frame nearly fills the GPU)
+            shape = kwargs.get("shape") or (kwargs["template"].shape if kwargs.get("template") is not None else (args[0] if args else None))
+            lanes = 8 if shape is not None and int(shape[0]) * int(shape[1]) <= 2048 * 2048 else 2
+        self.lanes = int(lanes)
         self._records_per_frame = 4096.0
         self._light = kwargs.get("profile") == "light"
         if kwargs.get("profile") and not self._light:

@@ -27,8 +27,15 @@ PAR = dict(InitSigma=1.6, BorderDist=5, Scales=3, PeakThresh=255.0 * 0.04 / 3.0,
            EdgeThresh1=0.08, OriSigma=1.5, MatchRatio=0.73, DoubleImSize=0)
 
 
-def available():
-    return os.path.exists(LIB_PATH)
+# Two builds of the same reference objects (oracle/Makefile): "glibc" binds the OpenCL math builtins to libm,
+# "siftmath" binds exp/sin/cos/atan2/pow(2,.) to the oracle's siftmath functions (libm isolated).
+LIB_PATHS = {"glibc": LIB_PATH, "siftmath": os.path.join(HERE, "_ref", "libsiftclref_sm.so")}
+_variant = "glibc"
+_libs = {}
+
+
+def available(variant=None):
+    return os.path.exists(LIB_PATHS[variant or _variant])
 
 
 def build():
@@ -37,16 +44,19 @@ def build():
     return available()
 
 
-_lib = None
+def use(variant):
+    """Select the build every function of this module drives: "glibc" (default) or "siftmath"."""
+    global _variant
+    assert variant in LIB_PATHS
+    _variant = variant
 
 
 def lib():
-    global _lib
-    if _lib is None:
+    if _variant not in _libs:
         if not available() and not build():
-            raise RuntimeError("oracle/_ref/libsiftclref.so is not built (needs /root/reference)")
-        _lib = C.CDLL(LIB_PATH)
-    return _lib
+            raise RuntimeError("%s is not built (needs /root/reference)" % LIB_PATHS[_variant])
+        _libs[_variant] = C.CDLL(LIB_PATHS[_variant])
+    return _libs[_variant]
 
 
 def _p(a):
@@ -132,6 +142,24 @@ def shrink(img):
     H, W = img.shape
     out = np.empty((H // 2, W // 2), np.float32)
     lib().ref_shrink(_p(img), _p(out), C.c_int(W), C.c_int(H), C.c_int(W // 2), C.c_int(H // 2))
+    return out
+
+
+_CONVERTERS = {"uint8": "ref_u8_to_float", "uint16": "ref_u16_to_float", "uint32": "ref_u32_to_float",
+               "uint64": "ref_u64_to_float", "int32": "ref_s32_to_float", "int64": "ref_s64_to_float"}
+
+
+def to_float(img):
+    """Integer / RGB frame -> float32 through the reference's converter kernels (preprocess.cl:53-223),
+    as plan.py:464-486 launches them."""
+    img = np.ascontiguousarray(img)
+    H, W = img.shape[:2]
+    out = np.empty((H, W), np.float32)
+    if img.ndim == 3:
+        assert img.dtype == np.uint8 and img.shape[2] == 3
+        lib().ref_rgb_to_float(_p(img), _p(out), C.c_int(W), C.c_int(H))
+    else:
+        getattr(lib(), _CONVERTERS[img.dtype.name])(_p(img), _p(out), C.c_int(W), C.c_int(H))
     return out
 
 

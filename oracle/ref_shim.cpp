@@ -42,15 +42,37 @@ void cl_barrier(unsigned) { if (g_barrier) pthread_barrier_wait(g_barrier); }
 int cl_atomic_inc(volatile int *p) __asm__("_Z10atomic_incPU8CLglobalVi");
 int cl_atomic_inc(volatile int *p) { return __atomic_fetch_add(p, 1, __ATOMIC_SEQ_CST); }
 
-// ---- math builtins -> glibc ------------------------------------------------------------------
+// ---- math builtins ---------------------------------------------------------------------------
+// Default build (libsiftclref.so): glibc libm.  -DREF_SIFTMATH (libsiftclref_sm.so): the five transcendental
+// builtins are bound to the oracle's siftmath functions instead.  OpenCL leaves their last bits to the
+// implementation, so either binding is "the reference"; the second one isolates libm: with it the reference's own
+// kernels must reproduce the oracle byte for byte, i.e. every residual of the default build is a libm last-bit choice.
+#ifdef REF_SIFTMATH
+extern "C" {
+#include "oracle_math.h"
+}
+static inline float sm_sin(float x) { float s, c; om_sincosf(x, &s, &c); return s; }
+static inline float sm_cos(float x) { float s, c; om_sincosf(x, &s, &c); return c; }
+float cl_exp(float x) __asm__("_Z3expf");       float cl_exp(float x) { return om_expf(x); }
+float cl_sin(float x) __asm__("_Z3sinf");       float cl_sin(float x) { return sm_sin(x); }
+float cl_cos(float x) __asm__("_Z3cosf");       float cl_cos(float x) { return sm_cos(x); }
+// the only pow() of the hot path is pow(2.0f, y) (image.cl:354)
+float cl_pow(float x, float y) __asm__("_Z3powff"); float cl_pow(float x, float y) { return x == 2.0f ? om_exp2f(y) : powf(x, y); }
+#else
 float cl_exp(float x) __asm__("_Z3expf");       float cl_exp(float x) { return expf(x); }
 float cl_sin(float x) __asm__("_Z3sinf");       float cl_sin(float x) { return sinf(x); }
 float cl_cos(float x) __asm__("_Z3cosf");       float cl_cos(float x) { return cosf(x); }
 float cl_pow(float x, float y) __asm__("_Z3powff"); float cl_pow(float x, float y) { return powf(x, y); }
+#endif
 float cl_fabs(float x) __asm__("_Z4fabsf");     float cl_fabs(float x) { return fabsf(x); }
 float cl_sqrt(float x) __asm__("_Z4sqrtf");     float cl_sqrt(float x) { return sqrtf(x); }
 float cl_rsqrt(float x) __asm__("_Z5rsqrtf");   float cl_rsqrt(float x) { return 1.0f / sqrtf(x); }
-float cl_atan2(float y, float x) __asm__("_Z5atan2ff"); float cl_atan2(float y, float x) { return atan2f(y, x); }
+float cl_atan2(float y, float x) __asm__("_Z5atan2ff");
+#ifdef REF_SIFTMATH
+float cl_atan2(float y, float x) { return om_atan2f(y, x); }
+#else
+float cl_atan2(float y, float x) { return atan2f(y, x); }
+#endif
 float cl_fmax(float a, float b) __asm__("_Z4fmaxff"); float cl_fmax(float a, float b) { return fmaxf(a, b); }
 float cl_fmin(float a, float b) __asm__("_Z4fminff"); float cl_fmin(float a, float b) { return fminf(a, b); }
 typedef float cl_float2 __attribute__((vector_size(8)));
@@ -65,6 +87,10 @@ void normalizes(float *image, const float *min_in, const float *max_in, const fl
 void shrink(const float *in, float *out, int sw, int sh, int LW, int LH, int SW, int SH);
 void u8_to_float(const unsigned char *in, float *out, int W, int H);
 void u16_to_float(const unsigned short *in, float *out, int W, int H);
+void u32_to_float(const unsigned int *in, float *out, int W, int H);
+void u64_to_float(const unsigned long *in, float *out, int W, int H);
+void s32_to_float(const int *in, float *out, int W, int H);
+void s64_to_float(const long *in, float *out, int W, int H);
 void rgb_to_float(const unsigned char *in, float *out, int W, int H);
 void horizontal_convolution(const float *in, float *out, float *filter, int hlen, int W, int H);
 void vertical_convolution(const float *in, float *out, float *filter, int hlen, int W, int H);
@@ -133,6 +159,18 @@ void ref_u8_to_float(const unsigned char *in, float *out, int W, int H) {
 }
 void ref_u16_to_float(const unsigned short *in, float *out, int W, int H) {
     run2d((size_t)W, (size_t)H, [&] { u16_to_float(in, out, W, H); });
+}
+void ref_u32_to_float(const unsigned int *in, float *out, int W, int H) {
+    run2d((size_t)W, (size_t)H, [&] { u32_to_float(in, out, W, H); });
+}
+void ref_u64_to_float(const unsigned long *in, float *out, int W, int H) {
+    run2d((size_t)W, (size_t)H, [&] { u64_to_float(in, out, W, H); });
+}
+void ref_s32_to_float(const int *in, float *out, int W, int H) {
+    run2d((size_t)W, (size_t)H, [&] { s32_to_float(in, out, W, H); });
+}
+void ref_s64_to_float(const long *in, float *out, int W, int H) {
+    run2d((size_t)W, (size_t)H, [&] { s64_to_float(in, out, W, H); });
 }
 void ref_rgb_to_float(const unsigned char *in, float *out, int W, int H) {
     run2d((size_t)W, (size_t)H, [&] { rgb_to_float(in, out, W, H); });

@@ -42,6 +42,7 @@ _SIGNATURES = {
                                      C.POINTER(C.c_void_p)]),
     "siftmi_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "siftmi_plan_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "siftmi_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "siftmi_plan_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "siftmi_plan_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),

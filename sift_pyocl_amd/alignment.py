@@ -1,17 +1,18 @@
-"""LinearAlign -- align images on a reference image with an affine transformation, on one MI355X.
+"""LinearAlign -- register images onto a reference frame with an affine map, on one MI355X.
 
-Mirror of the reference's ``sift_pyocl.LinearAlign`` (sift-src/alignment.py:76-360): same constructor
-keywords, ``align(img, shift_only, return_all, double_check, relative, orsa)`` contract and result
-dictionary.  The device work is SiftPlan.keypoints -> MatchPlan.match -> the affine warp kernel
-(openCL/transform.cl) reached through ``siftmi_plan_transform`` (include/siftmi.h); the image uploaded for
-keypoints() stays staged on the device and is the one the warp reads, as the reference's buffers["input"].
+Drop-in for the reference's ``sift_pyocl.LinearAlign`` (sift-src/alignment.py:76-360): constructor keywords,
+the ``align(img, shift_only, return_all, double_check, relative, orsa)`` contract and the keys of the
+``return_all`` dictionary are the reference's; the body is this package's own.  Device work per aligned frame:
+``SiftPlan.keypoints`` -> ``MatchPlan.match`` (both keypoint lists stay in HBM) -> the affine warp kernel
+(the arithmetic of openCL/transform.cl) through ``siftmi_plan_transform`` (include/siftmi.h).  The frame
+uploaded for ``keypoints()`` stays staged on the device and is the one the warp reads.
 
-Differences, all deliberate:
-  * ``utils.matching_correction`` is completed with a least-squares solve (the reference snapshot's function
-    ends before solving, see utils.py) -- so the affine branch works;
-  * the warp kernel covers the whole ``outshape`` (the reference launches one work-item per *input* pixel
-    and leaves the ``extra`` margin of its output buffer uninitialised);
-  * ``orsa`` needs the third-party ``feature`` module exactly as in the reference; absent -> warning.
+Behavioural notes (deliberate):
+  * the affine fit is a float64 least-squares solve (``utils.affine_least_squares``); the reference snapshot's
+    ``utils.matching_correction`` stops before solving (utils.py:156-189);
+  * the warp writes the whole ``outshape`` (the reference launches one work-item per *input* pixel and leaves
+    the ``extra`` margin of its output undefined);
+  * ``orsa=True`` needs the third-party ``feature`` module, exactly as in the reference; absent -> warning.
 """
 import ctypes as C
 import logging
@@ -31,94 +32,116 @@ try:
 except ImportError:
     feature = None
 
+#: a fit needs three correspondences per degree of freedom of the affine map (alignment.py:262)
+MIN_MATCHES_AFFINE = 3 * 6
+#: rejection threshold of ``double_check`` in standard deviations (alignment.py:291-293)
+OUTLIER_SIGMAS = 4
+
 
 def arrow_start(kplist):
-    """alignment.py:60-67"""
-    angle_ref = kplist.angle
-    scale_ref = kplist.scale
-    x_ref2 = kplist.x + scale_ref * numpy.cos(angle_ref)
-    y_ref2 = kplist.y + scale_ref * numpy.sin(angle_ref)
-    return x_ref2, y_ref2
+    """Tip of the scale/orientation arrow of every keypoint (reference helper, alignment.py:60-67):
+    (x + scale*cos(angle), y + scale*sin(angle))."""
+    length, theta = kplist.scale, kplist.angle
+    return kplist.x + length * numpy.cos(theta), kplist.y + length * numpy.sin(theta)
 
 
 def transform_pts(matrix, offset, x, y):
-    """alignment.py:70-73"""
-    nx = -offset[1] + y * matrix[1, 0] + x * matrix[1, 1]
-    ny = -offset[0] + x * matrix[0, 1] + y * matrix[0, 0]
-    return nx, ny
+    """Apply the (y, x)-ordered affine map of the warp kernel to points (reference helper, alignment.py:70-73).
+    Sums are formed in the reference's order so the float results are the same."""
+    m = numpy.asarray(matrix)
+    new_x = -offset[1] + y * m[1, 0] + x * m[1, 1]
+    new_y = -offset[0] + x * m[0, 1] + y * m[0, 0]
+    return new_x, new_y
+
+
+def _as_yx_pair(extra):
+    """``extra`` margin as a (y, x) tuple of ints; a scalar applies to both axes"""
+    if hasattr(extra, "__len__"):
+        return tuple(int(v) for v in extra[:2])
+    return (int(extra),) * 2
+
+
+def _zscore_flags(values, limit=OUTLIER_SIGMAS):
+    """1 where a sample lies more than `limit` standard deviations from the mean (NaN z-scores compare False)"""
+    with numpy.errstate(divide="ignore", invalid="ignore"):
+        return (abs((values - values.mean()) / values.std()) > limit).astype(numpy.int8)
 
 
 class LinearAlign(object):
-    """Align images on a reference image based on an afine transformation (bi-linear + offset)"""
+    """Align images on a reference image based on an affine transformation (bi-linear + offset)"""
 
     def __init__(self, image, devicetype="GPU", profile=False, device=None, max_workgroup_size=None,
                  ROI=None, extra=0, context=None, init_sigma=None):
         """
-        :param image: reference image on which other image should be aligned
-        :param devicetype, max_workgroup_size, context: accepted for source compatibility, unused
-        :param profile: collect kernel timings
-        :param device: HIP device ordinal (default: LOCAL_RANK or 0)
-        :param ROI: boolean mask of the region where reference keypoints are kept
-        :param extra: extra space around the image, an integer or a 2-tuple in YX convention
-        :param init_sigma: bluring width, you should have good reasons to modify the 1.6 default value...
+        :param image: reference image on which the other images are aligned (2-D float-able, or H x W x 3 uint8)
+        :param devicetype, max_workgroup_size, context: accepted for source compatibility with the reference, unused
+        :param profile: collect kernel timings (``log_profile``)
+        :param device: HIP device ordinal (default: SIFT_MI355X_DEVICE, LOCAL_RANK or 0)
+        :param ROI: boolean mask; reference keypoints outside it are dropped
+        :param extra: margin added around the output, an integer or a (y, x) pair
+        :param init_sigma: blur width of the initial smoothing (default ``par.InitSigma`` = 1.6)
         """
+        ndim = len(image.shape)
+        if ndim not in (2, 3):
+            raise RuntimeError("Unable to process image of shape %s" % (tuple(image.shape,)))
+        self.RGB = ndim == 3
+        self.shape = tuple(int(v) for v in image.shape[:2])
+        self.extra = _as_yx_pair(extra)
+        self.outshape = (self.shape[0] + 2 * self.extra[0], self.shape[1] + 2 * self.extra[1])
         self.profile = bool(profile)
         self.events = []
         self.ref = numpy.ascontiguousarray(image, numpy.float32)
-        self.shape = image.shape
-        if len(self.shape) == 3:
-            self.RGB = True
-            self.shape = self.shape[:2]
-        elif len(self.shape) == 2:
-            self.RGB = False
-        else:
-            raise RuntimeError("Unable to process image of shape %s" % (tuple(self.shape,)))
-        self.shape = tuple(int(i) for i in self.shape)
-        if "__len__" not in dir(extra):
-            self.extra = (int(extra), int(extra))
-        else:
-            self.extra = tuple(int(i) for i in extra[:2])
-        self.outshape = tuple(i + 2 * j for i, j in zip(self.shape, self.extra))
         self.ROI = ROI
         self.ctx = context
-        if isinstance(device, (tuple, list)):
-            device = device[-1]
-        if device is None:
-            device = int(os.environ.get("SIFT_MI355X_DEVICE", os.environ.get("LOCAL_RANK", 0)))
-        self.device = int(device)
         self.devicetype = "GPU"
         self.max_workgroup_size = max_workgroup_size
+        if isinstance(device, (tuple, list)):       # the reference's (platform, device) pair: keep the device index
+            device = device[-1]
+        if device is None:
+            device = os.environ.get("SIFT_MI355X_DEVICE", os.environ.get("LOCAL_RANK", 0))
+        self.device = int(device)
         self.sift = SiftPlan(template=image, device=self.device, profile=self.profile, init_sigma=init_sigma)
-        self.ref_kp = self._mask(self.sift.keypoints(image))
         self.match = MatchPlan(device=self.device, profile=self.profile)
-        self._ref_dev = None
-        self._upload_ref()
         self.fill_value = 0
         self.sem = threading.Semaphore()
         self.relative_transfo = None
         self.last_transform_ms = 0.0
+        self._ref_dev = None
+        self._set_reference(self.sift.keypoints(image))
+
+    # ------------------------------------------------------------------ reference keypoints
+    def _set_reference(self, kp):
+        """Install `kp` (ROI-filtered) as the reference list and keep a copy resident on the device
+        (the reference's buffers["ref_kp_gpu"], alignment.py:155-157)."""
+        self.ref_kp = self._mask(kp)
+        self._upload_ref()
 
     def _upload_ref(self):
-        """Reference keypoints resident on the device (alignment.py:155-157: buffers["ref_kp_gpu"]); needs torch for
-        the allocation, otherwise the host list is sent with every match."""
+        """Device copy of the reference keypoints.  torch is only the allocator here: without it, or without a
+        visible device, the host list is handed to every match() call instead."""
         self._ref_dev = None
+        if not self.ref_kp.size:
+            return
         try:
             import torch
-            if self.ref_kp.size:
-                raw = numpy.ascontiguousarray(self.ref_kp).view(numpy.uint8).reshape(-1)
-                self._ref_dev = torch.from_numpy(raw.copy()).to("cuda:%d" % self.device)
-        except ImportError:
-            pass
+            if not torch.cuda.is_available():
+                return
+            raw = numpy.ascontiguousarray(self.ref_kp).view(numpy.uint8).reshape(-1)
+            self._ref_dev = torch.from_numpy(raw.copy()).to("cuda:%d" % self.device)
+        except Exception as err:  # noqa: BLE001 -- any allocator problem: fall back to the host list
+            logger.debug("reference keypoints stay on the host (%s)", err)
+            self._ref_dev = None
 
     def _mask(self, kp):
         if self.ROI is None:
             return kp
-        kpx = numpy.round(kp.x).astype(numpy.int32)
-        kpy = numpy.round(kp.y).astype(numpy.int32)
-        masked = self.ROI[(kpy, kpx)].astype(bool)
-        logger.warning("Reducing keypoint list from %i to %i because of the ROI" % (kp.size, masked.sum()))
-        return kp[masked]
+        col = numpy.round(kp.x).astype(numpy.int32)
+        row = numpy.round(kp.y).astype(numpy.int32)
+        inside = self.ROI[(row, col)].astype(bool)
+        logger.warning("Reducing keypoint list from %i to %i because of the ROI" % (kp.size, inside.sum()))
+        return kp[inside]
 
+    # ------------------------------------------------------------------ device warp
     def transform(self, matrix, offset, image=None, fill=None, mode=1):
         """Affine warp on the device (transform.cl).  image=None warps the image staged by the last keypoints()."""
         matrix = numpy.ascontiguousarray(matrix, numpy.float32).reshape(4)
@@ -143,105 +166,7 @@ class LinearAlign(object):
             self.events.append(("transform", ms.value))
         return out
 
-    def align(self, img, shift_only=False, return_all=False, double_check=False, relative=False, orsa=False):
-        """
-        Align image on reference image
-
-        :param img: numpy array containing the image to align to reference
-        :param return_all: return in addition ot the image, keypoints, matching keypoints, and transformations as a dict
-        :param relative: update reference keypoints with those from current image to perform relative alignment
-        :return: aligned image or all informations
-        """
-        logger.debug("ref_keypoints: %s" % self.ref_kp.size)
-        if self.RGB:
-            data = numpy.ascontiguousarray(img, numpy.uint8)
-        else:
-            data = numpy.ascontiguousarray(img, numpy.float32)
-        with self.sem:
-            kp = self.sift.keypoints(data)          # uploads `data`; it stays staged on the device for the warp
-            logger.debug("mod image keypoints: %s" % kp.size)
-            # both lists are matched where they lie in HBM: the reference list uploaded once, the new one still in the plan
-            raw_matching = self.match.match(self._ref_dev if self._ref_dev is not None else self.ref_kp,
-                                            self.sift.device_records() if kp.size else kp, raw_results=True)
-            len_match = raw_matching.shape[0]
-            if len_match == 0:
-                logger.warning("No matching keypoints")
-                return
-            # Only (x, y, scale, angle) of the matched keypoints enter the fit: gather those 16 bytes per keypoint
-            # instead of the 144-byte records; the `matching` recarray of the reference (alignment.py:254-259) is
-            # built lazily, for ORSA and for return_all.
-            g0 = self._xysa(self.ref_kp)[raw_matching[:, 0]]
-            g1 = self._xysa(kp)[raw_matching[:, 1]]
-            matching = None
-            ref_kp_used = self.ref_kp
-
-            def full_matching():
-                m = numpy.recarray(shape=raw_matching.shape, dtype=MatchPlan.dtype_kp)
-                m[:, 0] = ref_kp_used[raw_matching[:, 0]]
-                m[:, 1] = kp[raw_matching[:, 1]]
-                return m
-
-            if orsa:
-                if feature:
-                    matching = feature.sift_orsa(full_matching(), self.shape, 1)
-                    g0 = numpy.stack([matching[:, 0].x, matching[:, 0].y, matching[:, 0].scale, matching[:, 0].angle], axis=1)
-                    g1 = numpy.stack([matching[:, 1].x, matching[:, 1].y, matching[:, 1].scale, matching[:, 1].angle], axis=1)
-                else:
-                    logger.warning("feature is not available. No ORSA filtering")
-
-            if (len_match < 3 * 6) or (shift_only):  # 3 points per DOF
-                if shift_only:
-                    logger.debug("Shift Only mode: Common keypoints: %s" % len_match)
-                else:
-                    logger.warning("Shift Only mode: Common keypoints: %s" % len_match)
-                dx = g1[:, 0] - g0[:, 0]
-                dy = g1[:, 1] - g0[:, 1]
-                matrix = numpy.identity(2, dtype=numpy.float32)
-                offset = numpy.array([+numpy.median(dy), +numpy.median(dx)], numpy.float32)
-            else:
-                logger.debug("Common keypoints: %s" % len_match)
-                matrix, offset = self._affine(g0, g1)
-            if double_check and (len_match >= 3 * 6):
-                logger.warning("Validating keypoints, %s,%s" % (matrix, offset))
-                dx = g1[:, 0] - g0[:, 0]
-                dy = g1[:, 1] - g0[:, 1]
-                dangle = g1[:, 3] - g0[:, 3]
-                dscale = numpy.log(g1[:, 2] / g0[:, 2])
-                distance = numpy.sqrt(dx * dx + dy * dy)
-                outlayer = numpy.zeros(distance.shape, numpy.int8)
-                outlayer += abs((distance - distance.mean()) / distance.std()) > 4
-                outlayer += abs((dangle - dangle.mean()) / dangle.std()) > 4
-                outlayer += abs((dscale - dscale.mean()) / dscale.std()) > 4
-                outlayersum = outlayer.sum()
-                if outlayersum > 0 and not numpy.isinf(outlayersum):
-                    keep = outlayer == 0
-                    matrix, offset = self._affine(g0[keep], g1[keep])
-            if relative:  # update stable part to perform a relative alignment
-                self.ref_kp = self._mask(kp)
-                self._upload_ref()
-                transfo = numpy.zeros((3, 3), dtype=numpy.float64)
-                transfo[:2, :2] = matrix
-                transfo[0, 2] = offset[0]
-                transfo[1, 2] = offset[1]
-                transfo[2, 2] = 1
-                if self.relative_transfo is None:
-                    self.relative_transfo = transfo
-                else:
-                    self.relative_transfo = numpy.dot(transfo, self.relative_transfo)
-                matrix = numpy.ascontiguousarray(self.relative_transfo[:2, :2], dtype=numpy.float32)
-                offset = numpy.ascontiguousarray(self.relative_transfo[:2, 2], dtype=numpy.float32)
-            result = self.transform(matrix, offset, image=None, fill=self.sift.minmax()[0], mode=1)
-
-        if return_all:
-            corr = numpy.dot(matrix, numpy.vstack((g0[:, 1], g0[:, 0]))).T + offset.T - numpy.vstack((g1[:, 1], g1[:, 0])).T
-            rms = numpy.sqrt((corr * corr).sum(axis=-1).mean())
-            if matching is None:
-                matching = full_matching()
-            return {"result": result, "keypoint": kp, "matching": matching, "offset": offset, "matrix": matrix, "rms": rms}
-        return result
-
-    __call__ = align
-
+    # ------------------------------------------------------------------ host-side estimation
     @staticmethod
     def _xysa(kp):
         """(n, 4) float32 view of (x, y, scale, angle) of a keypoint array (no copy for contiguous records)"""
@@ -250,20 +175,122 @@ class LinearAlign(object):
 
     @staticmethod
     def _affine(g0, g1):
-        """alignment.py:279-283: (a..f) of matching_correction -> the (y, x)-ordered matrix / offset of the kernel"""
-        t = affine_least_squares(g0[:, 0], g0[:, 1], g1[:, 0], g1[:, 1])
-        offset = numpy.array([t[5], t[2]], dtype=numpy.float32)
-        matrix = numpy.empty((2, 2), dtype=numpy.float32)
-        matrix[0, 0], matrix[0, 1] = t[4], t[3]
-        matrix[1, 0], matrix[1, 1] = t[1], t[0]
-        return matrix, offset
+        """Least-squares affine map g0 -> g1, returned in the kernel's (y, x) ordering: the six coefficients
+        (a..f) of matching_correction are unpacked as in alignment.py:279-283."""
+        a, b, c, d, e, f = affine_least_squares(g0[:, 0], g0[:, 1], g1[:, 0], g1[:, 1])[:6]
+        return numpy.array([[e, d], [b, a]], dtype=numpy.float32), numpy.array([f, c], dtype=numpy.float32)
+
+    @staticmethod
+    def _median_shift(g0, g1):
+        """Translation-only estimate: identity matrix and the median displacement, (dy, dx) order (alignment.py:268-271)"""
+        delta = g1[:, :2] - g0[:, :2]
+        return numpy.identity(2, dtype=numpy.float32), numpy.array([numpy.median(delta[:, 1]), numpy.median(delta[:, 0])], numpy.float32)
+
+    @staticmethod
+    def _inliers(g0, g1):
+        """double_check (alignment.py:284-296): a pair is an outlier when its displacement length, its angle
+        difference or its log scale ratio lies more than OUTLIER_SIGMAS standard deviations from the mean.
+        Returns the boolean keep mask, or None when nothing is to be rejected."""
+        shift = g1[:, :2] - g0[:, :2]
+        votes = _zscore_flags(numpy.sqrt(shift[:, 0] * shift[:, 0] + shift[:, 1] * shift[:, 1]))
+        votes = votes + _zscore_flags(g1[:, 3] - g0[:, 3])
+        votes = votes + _zscore_flags(numpy.log(g1[:, 2] / g0[:, 2]))
+        rejected = votes.sum()
+        if rejected > 0 and not numpy.isinf(rejected):
+            return votes == 0
+        return None
+
+    def _chain_relative(self, matrix, offset):
+        """relative=True: compose this frame's map with the maps of the previous frames (homogeneous 3x3 product,
+        newest on the left, alignment.py:309-318) and return the accumulated matrix / offset."""
+        step = numpy.identity(3, dtype=numpy.float64)
+        step[:2, :2] = matrix
+        step[:2, 2] = offset
+        self.relative_transfo = step if self.relative_transfo is None else numpy.dot(step, self.relative_transfo)
+        return (numpy.ascontiguousarray(self.relative_transfo[:2, :2], dtype=numpy.float32),
+                numpy.ascontiguousarray(self.relative_transfo[:2, 2], dtype=numpy.float32))
+
+    # ------------------------------------------------------------------ public entry
+    def align(self, img, shift_only=False, return_all=False, double_check=False, relative=False, orsa=False):
+        """Align `img` on the reference image.
+
+        :param img: image to align (same shape as the reference)
+        :param shift_only: estimate a translation only (also the fallback below 18 matches)
+        :param return_all: return a dict with result / keypoint / matching / offset / matrix / rms instead of the image
+        :param double_check: re-fit after rejecting 4-sigma outliers in displacement, angle and scale
+        :param relative: make this frame the reference of the next one and accumulate the transformations
+        :param orsa: filter the matches with ``feature.sift_orsa`` when that module is importable
+        :return: the aligned image, the dict, or None when no keypoint matches
+        """
+        logger.debug("ref_keypoints: %s" % self.ref_kp.size)
+        data = numpy.ascontiguousarray(img, numpy.uint8 if self.RGB else numpy.float32)
+        with self.sem:
+            kp = self.sift.keypoints(data)          # uploads `data`; it stays staged on the device for the warp
+            logger.debug("mod image keypoints: %s" % kp.size)
+            # both lists are matched where they lie in HBM: the reference list uploaded once, the new one still in the plan
+            ref_list = self.ref_kp if self._ref_dev is None else self._ref_dev
+            pairs = self.match.match(ref_list, self.sift.device_records() if kp.size else kp, raw_results=True)
+            n_pairs = pairs.shape[0]
+            if n_pairs == 0:
+                logger.warning("No matching keypoints")
+                return None
+            # Only (x, y, scale, angle) of the matched keypoints enter the fit: 16 bytes per keypoint are gathered, not
+            # the 144-byte records; the reference's `matching` recarray (alignment.py:254-259) is only materialised for
+            # ORSA and for return_all.
+            ref_used = self.ref_kp
+            g0 = self._xysa(ref_used)[pairs[:, 0]]
+            g1 = self._xysa(kp)[pairs[:, 1]]
+
+            def matched_records():
+                both = numpy.recarray(shape=pairs.shape, dtype=MatchPlan.dtype_kp)
+                both[:, 0] = ref_used[pairs[:, 0]]
+                both[:, 1] = kp[pairs[:, 1]]
+                return both
+
+            matching = None
+            if orsa and feature is None:
+                logger.warning("feature is not available. No ORSA filtering")
+            elif orsa:
+                matching = feature.sift_orsa(matched_records(), self.shape, 1)
+                g0, g1 = self._xysa(numpy.ascontiguousarray(matching[:, 0])), self._xysa(numpy.ascontiguousarray(matching[:, 1]))
+
+            enough = n_pairs >= MIN_MATCHES_AFFINE
+            if shift_only or not enough:
+                (logger.debug if shift_only else logger.warning)("Shift Only mode: Common keypoints: %s" % n_pairs)
+                matrix, offset = self._median_shift(g0, g1)
+            else:
+                logger.debug("Common keypoints: %s" % n_pairs)
+                matrix, offset = self._affine(g0, g1)
+            if double_check and enough:
+                logger.warning("Validating keypoints, %s,%s" % (matrix, offset))
+                keep = self._inliers(g0, g1)
+                if keep is not None:
+                    matrix, offset = self._affine(g0[keep], g1[keep])
+            if relative:
+                self._set_reference(kp)             # this frame becomes the reference of the next one
+                matrix, offset = self._chain_relative(matrix, offset)
+            result = self.transform(matrix, offset, image=None, fill=self.sift.minmax()[0], mode=1)
+
+        if not return_all:
+            return result
+        # residual of the fitted map on the matched keypoints, in pixels (alignment.py:349-351)
+        src_yx = numpy.stack((g0[:, 1], g0[:, 0]))
+        dst_yx = numpy.stack((g1[:, 1], g1[:, 0]))
+        resid = numpy.dot(matrix, src_yx).T + offset.T - dst_yx.T
+        rms = numpy.sqrt((resid * resid).sum(axis=-1).mean())
+        if matching is None:
+            matching = matched_records()
+        return {"result": result, "keypoint": kp, "matching": matching, "offset": offset, "matrix": matrix, "rms": rms}
+
+    __call__ = align
 
     def log_profile(self):
-        """If we are in debugging mode, prints out all timing for every single kernel call"""
-        t = 0.0
-        if self.profile:
-            for name, ms in self.events:
-                print("%50s:\t%.3fms" % (name, ms))
-                t += ms
-            print("_" * 80)
-            print("%50s:\t%.3fms" % ("Total execution time", t))
+        """Print the timing of every recorded device call (profile=True)"""
+        if not self.profile:
+            return
+        total = 0.0
+        for name, ms in self.events:
+            print("%50s:\t%.3fms" % (name, ms))
+            total += ms
+        print("_" * 80)
+        print("%50s:\t%.3fms" % ("Total execution time", total))

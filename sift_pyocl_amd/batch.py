@@ -129,7 +129,7 @@ class BatchPlan(SiftPlan):
             self.overflow = bool(ovf.value)
             if self.overflow:
                 logger.warning("Keypoint counter overflow: more than %s keypoints in a frame, result truncated", self.kpsize)
-            flat = None
+            flat = numpy.empty(0, dtype=self.dtype_kp)      # a batch of blank frames parks nothing
             if parked.value:
                 flat = numpy.empty(parked.value, dtype=self.dtype_kp)
                 _lib.check(L.siftmi_batch_fetch(self._handle, flat.ctypes.data, 0, 0, parked.value))

@@ -82,6 +82,24 @@ int kernel_size(double sigma) {   // utils.py:54-64 with odd=True, cutoff=4
 
 struct Taps { int n = 0; float t[64] = {0}; float *dev = nullptr; };
 
+// Per-plan tuning / diagnostic options (siftmi_plan_set_option).  Defaults are the measured best; nothing on the launch
+// path reads the environment.
+struct Options {
+    int fused_convert = 1;   // typed frames converted at the point of use (0: separate convert pass)
+    int overlap = 1;         // detection / description streams beside the pyramid stream (0: one stream)
+    int march = 1;           // marching blur for large planes (0: tiled blur everywhere)
+    int team = 1;            // team form of the marching blur (0: one-block form)
+    int march_nt = 128;      // threads per workgroup of the one-block form (64 or 128)
+    int march_wgs = 0;       // workgroups wanted by the one-block form (0: default)
+    int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
+    int ori_blocks = 1024, ori_pad = 0;
+    int desc_blocks = 2048, desc_pad = -1;   // -1: residency heuristic
+    int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
+    int spin = 1;            // poll the ending streams instead of a blocking wait
+    int host_timing = 0;     // print the host time of plan_enqueue
+};
+const Options g_default_options{};
+
 struct Event { std::string label; hipEvent_t a = nullptr, b = nullptr; bool is_blur = false; double pixels = 0; int octave = -1; int launches = 1; };
 
 size_t dtype_size(int dt) {
@@ -101,6 +119,7 @@ struct siftmi_plan {
     hipStream_t stream = nullptr;
     int H = 0, W = 0, dtype = 0;
     siftmi_params par{};
+    Options opt;
     int profile = 0;
     int n_oct = 0;
     std::vector<int> ow, oh;
@@ -195,18 +214,18 @@ void launch_blur_t(hipStream_t st, const void *in, float *out, int W, int H, con
 }
 
 template <int N, bool NORM, int NT, int DT = 0>
-void launch_march_nt(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+void launch_march_nt(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
     using G = MarchGeom<N, NT>;
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     const int gx = (W + G::TX - 1) / G::TX;
     // pick the segment height: enough workgroups to fill 256 CUs, warm-up overhead (N-1)/rows kept low
-    static const int want_wgs = getenv("SIFTMI_MARCH_WGS") ? atoi(getenv("SIFTMI_MARCH_WGS")) : 1024 * 128 / NT;
+    const int want_wgs = opt.march_wgs > 0 ? opt.march_wgs : 1024 * 128 / NT;
     int want_segments = (want_wgs + gx - 1) / gx;
     int rows = (H + want_segments - 1) / want_segments;
     int nblocks = (rows + (N - 1) + N - 1) / N;
     if (nblocks < 3) nblocks = 3;
-    if (const char *e = getenv("SIFTMI_MARCH_NB")) nblocks = atoi(e);   // dev tuning knob
+    if (opt.march_nb > 0) nblocks = opt.march_nb;
     const int rows_out = nblocks * N - (N - 1);
     dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
     hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT, DT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
@@ -230,14 +249,12 @@ void launch_team(hipStream_t st, const void *in, float *out, int W, int H, const
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
 // plane (tools/ubench/blur_team.hip: 31 / 38 / 41 / 47 / 65 us against 33 / 43 / 45 / 53 / 73 us for the one-block form);
-// SIFTMI_NO_TEAM=1 (dev knob) falls back to the one-block marching kernel.
+// option "team" = 0 falls back to the one-block marching kernel.
 template <int N, bool NORM, int DT = 0>
-void launch_march_t(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
-    static const bool no_team = getenv("SIFTMI_NO_TEAM") != nullptr;
-    if (no_team) {
-        static const int nt = getenv("SIFTMI_MARCH_NT") ? atoi(getenv("SIFTMI_MARCH_NT")) : 128;   // dev knob: 64 = one wave per workgroup
-        if (nt == 64) launch_march_nt<N, NORM, 64, DT>(st, in, out, W, H, taps, mm);
-        else launch_march_nt<N, NORM, 128, DT>(st, in, out, W, H, taps, mm);
+void launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+    if (!opt.team) {
+        if (opt.march_nt == 64) launch_march_nt<N, NORM, 64, DT>(opt, st, in, out, W, H, taps, mm);
+        else launch_march_nt<N, NORM, 128, DT>(opt, st, in, out, W, H, taps, mm);
         return;
     }
     constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
@@ -246,16 +263,16 @@ void launch_march_t(hipStream_t st, const void *in, float *out, int W, int H, co
 
 // returns false when no tiled instantiation exists for this tap count
 template <bool NORM>
-bool launch_blur_tiled(hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
+bool launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
     bool symmetric = true;
     for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
-    if (W >= 1024 && H >= 512 && symmetric && !getenv("SIFTMI_NO_MARCH")) {
+    if (W >= 1024 && H >= 512 && symmetric && opt.march) {
         switch (t.n) {
-            case 11: launch_march_t<11, NORM>(st, in, out, W, H, t.t, mm); return true;
-            case 15: launch_march_t<15, NORM>(st, in, out, W, H, t.t, mm); return true;
-            case 17: launch_march_t<17, NORM>(st, in, out, W, H, t.t, mm); return true;
-            case 21: launch_march_t<21, NORM>(st, in, out, W, H, t.t, mm); return true;
-            case 27: launch_march_t<27, NORM>(st, in, out, W, H, t.t, mm); return true;
+            case 11: launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+            case 15: launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+            case 17: launch_march_t<17, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+            case 21: launch_march_t<21, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+            case 27: launch_march_t<27, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
             default: break;
         }
     }
@@ -277,8 +294,8 @@ void launch_blur_generic(hipStream_t st, const float *in, float *out, float *tmp
 }
 
 void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm) {
-    bool ok = norm ? launch_blur_tiled<true>(p->stream, in, out, W, H, t, p->mm)
-                   : launch_blur_tiled<false>(p->stream, in, out, W, H, t, p->mm);
+    bool ok = norm ? launch_blur_tiled<true>(p->opt, p->stream, in, out, W, H, t, p->mm)
+                   : launch_blur_tiled<false>(p->opt, p->stream, in, out, W, H, t, p->mm);
     if (!ok) launch_blur_generic(p->stream, in, out, p->tmp, W, H, t, p->mm, norm);
 }
 
@@ -291,10 +308,10 @@ bool taps_symmetric(const Taps &t) {
 // Initial blur reading a typed (integer / RGB) frame directly: instantiated for the default 15-tap initial
 // kernel (init_sigma = 1.6); any other tap count goes through the convert pass.
 template <int DT>
-bool launch_init_blur_dt(hipStream_t st, const void *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
+bool launch_init_blur_dt(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
     if (t.n != 15) return false;
-    if (W >= 1024 && H >= 512 && taps_symmetric(t) && !getenv("SIFTMI_NO_MARCH"))
-        launch_march_t<15, true, DT>(st, in, out, W, H, t.t, mm);
+    if (W >= 1024 && H >= 512 && taps_symmetric(t) && opt.march)
+        launch_march_t<15, true, DT>(opt, st, in, out, W, H, t.t, mm);
     else
         launch_blur_t<15, true, DT>(st, in, out, W, H, t.t, mm);
     return true;
@@ -388,8 +405,7 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
     {
         snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
         Scope sc(p, lab, false, 0, st);
-        static const int ori_blocks = getenv("SIFTMI_ORI_BLOCKS") ? atoi(getenv("SIFTMI_ORI_BLOCKS")) : 1024;   // dev knob
-        static const int ori_pad = getenv("SIFTMI_ORI_PAD") ? atoi(getenv("SIFTMI_ORI_PAD")) : 0;   // dev knob
+        const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
         hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
                            (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap);
     }
@@ -398,13 +414,13 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
     {
         snprintf(lab, sizeof lab, "descriptors group %d", group);
         Scope sc(p, lab, false, 0, st);
-        static const int desc_blocks = getenv("SIFTMI_DESC_BLOCKS") ? atoi(getenv("SIFTMI_DESC_BLOCKS")) : 2048;   // dev knob
+        const int desc_blocks = p->opt.desc_blocks;
         // Residency throttle.  With few keypoints (a white-noise 4096^2 frame has ~8 k in octave 0) the descriptor kernel is
         // not the bottleneck, but at full occupancy (5 waves per SIMD x 96 VGPRs) it leaves no registers for the
         // later octaves' blur / detection kernels, whose chain then trails it by > 100 us.  20 KB of unused dynamic LDS
         // cap it at 3 blocks per CU; the later-octave kernels slip in (-4 % per image).  Keypoint-dense frames
         // (> 20 k in octave 0, judged by the previous frame of this plan) are descriptor-bound and run unthrottled (+12 %).
-        static const int desc_pad_env = getenv("SIFTMI_DESC_PAD") ? atoi(getenv("SIFTMI_DESC_PAD")) : -1;   // dev knob
+        const int desc_pad_env = p->opt.desc_pad;
         int desc_pad = (group == 0 && p->overlap && p->n_oct > 1 && p->last_group0 <= 20000) ? 20000 : 0;
         if (desc_pad_env >= 0) desc_pad = desc_pad_env;
         hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
@@ -479,9 +495,8 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     // (BatchPlan with 2 lanes of large frames: 1.13 instead of 1.33 ms per 4096^2 frame); for a single plan they are
     // within noise, and once a process has created prioritised streams its normal-priority streams get fewer hardware
     // queues (8 single-stream lanes of 512^2 frames: 0.72 instead of 0.41 ms per frame).  Hence: only for the
-    // multi-stream lanes of a batch; SIFTMI_PRIO=1 forces them for plain plans (dev knob).
-    static const bool prio_env = getenv("SIFTMI_PRIO") != nullptr;
-    const bool prio = prio_env || g_lane_mode == 2;
+    // multi-stream lanes of a batch.
+    const bool prio = g_lane_mode == 2;
     int prio_lo = 0, prio_hi = 0;
     if (prio) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     hipError_t e = prio ? hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
@@ -496,7 +511,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
     if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_grp1, hipEventDisableTiming) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
-    p->overlap = getenv("SIFTMI_SINGLE_STREAM") == nullptr;
+    p->overlap = true;
     for (int o = 0; o < p->n_oct && !rc; o++) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
@@ -557,13 +572,41 @@ int siftmi_plan_info(const siftmi_plan *p, int32_t *n_octaves, int64_t *kpsize, 
 
 int siftmi_plan_set_params(siftmi_plan *p, const siftmi_params *params) {
     if (!p || !params) return fail(SIFTMI_EINVAL, "null argument");
-    if (params->pix_per_kp != p->par.pix_per_kp || params->border_dist != p->par.border_dist ||
-        params->octave_max != p->par.octave_max)
-        return fail(SIFTMI_EINVAL, "pix_per_kp / border_dist / octave_max are fixed at plan creation");
+    if (params->pix_per_kp != p->par.pix_per_kp || params->octave_max != p->par.octave_max)
+        return fail(SIFTMI_EINVAL, "pix_per_kp / octave_max are fixed at plan creation");
+    // border_dist may change between calls: like the reference, which sizes its octave list from par.BorderDist in the
+    // constructor (plan.py:213-224) but hands the CURRENT par.BorderDist to local_maxmin (plan.py:631-641), the octave
+    // shapes stay those of creation and only the detection border follows.
+    if (params->border_dist < 1) return fail(SIFTMI_EINVAL, "border_dist must be >= 1");
     HIPCHK(hipSetDevice(p->device));
     const bool resched = params->init_sigma != p->par.init_sigma;
     p->par = *params;
     return resched ? compute_schedule(p) : SIFTMI_OK;
+}
+
+// Tuning / diagnostic options of one plan, by name.  Results never depend on them (every path is bit-identical);
+// tests use "fused_convert" = 0 to compare the fused typed-frame path with the separate convert pass.
+int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
+    if (!p || !name) return fail(SIFTMI_EINVAL, "null argument");
+    const std::string n(name);
+    const int v = (int)value;
+    Options &o = p->opt;
+    if (n == "fused_convert") o.fused_convert = v != 0;
+    else if (n == "overlap") { o.overlap = v != 0; p->overlap = o.overlap; }
+    else if (n == "march") o.march = v != 0;
+    else if (n == "team") o.team = v != 0;
+    else if (n == "march_nt") { if (v != 64 && v != 128) return fail(SIFTMI_EINVAL, "march_nt must be 64 or 128"); o.march_nt = v; }
+    else if (n == "march_wgs") o.march_wgs = v > 0 ? v : 0;
+    else if (n == "march_nb") o.march_nb = v >= 3 ? v : 0;
+    else if (n == "ori_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_blocks must be >= 1"); o.ori_blocks = v; }
+    else if (n == "ori_pad") o.ori_pad = v > 0 ? v : 0;
+    else if (n == "desc_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_blocks must be >= 1"); o.desc_blocks = v; }
+    else if (n == "desc_pad") o.desc_pad = v;
+    else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
+    else if (n == "spin") o.spin = v != 0;
+    else if (n == "host_timing") o.host_timing = v != 0;
+    else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
+    return SIFTMI_OK;
 }
 
 }  // extern "C"
@@ -588,7 +631,7 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
         src = p->raw;
         p->raw_dtype = image_dtype;
     }
-    const bool htime = getenv("SIFTMI_HOST_TIMING") != nullptr;
+    const bool htime = p->opt.host_timing != 0;
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_enter = tnow();
     p->n_events = 0;
@@ -602,7 +645,7 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
     // (or the plain normalise) -- no f32 copy of the frame in HBM.  Fallback to the convert pass: float64 frames,
     // a non-default initial tap count, a frame that is not 16-byte aligned.
     const bool fused_in = image_dtype != SIFTMI_F32 && image_dtype != SIFTMI_F64 && (((uintptr_t)src) & 15) == 0 &&
-                          (!p->have_init || p->taps[5].n == 15) && !getenv("SIFTMI_NO_FUSED_CONVERT");
+                          (!p->have_init || p->taps[5].n == 15) && p->opt.fused_convert;
     if (image_dtype != SIFTMI_F32 && !fused_in) {
         Scope sc(p, "convert -> float");
         const int g = grid_for((int64_t)N, 256, 4096);
@@ -619,8 +662,7 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
         }
         f32src = p->conv;
     }
-    // few, fat workgroups: every block ends with two atomics on the same cache line
-    static const int mm_blocks = getenv("SIFTMI_MM_BLOCKS") ? atoi(getenv("SIFTMI_MM_BLOCKS")) : 256;
+    const int mm_blocks = p->opt.mm_blocks;
     {
         Scope sc(p, "max_min");
         if (fused_in) {
@@ -642,7 +684,7 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
             p->chain = ch;
         } else sc = new Scope(p, "normalize + initial blur", true, (double)N, nullptr, 0);
         if (fused_in) {
-            SIFTMI_TYPED_DISPATCH(image_dtype, launch_init_blur_dt<DT>(p->stream, src, base0, p->W, p->H, p->taps[5], p->mm));
+            SIFTMI_TYPED_DISPATCH(image_dtype, launch_init_blur_dt<DT>(p->opt, p->stream, src, base0, p->W, p->H, p->taps[5], p->mm));
         } else {
             launch_blur(p, f32src, base0, p->W, p->H, p->taps[5], true);
         }
@@ -712,6 +754,7 @@ int enqueue_body(siftmi_plan *p) {
             if (p->overlap) HIPCHK(hipEventRecord(p->ev_grp1, dst));
         }
     }
+    if (p->chain) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }   // no octave closed the light-profile bracket (n_oct == 0)
     // Both detection streams rejoin the pyramid stream, which ends the image with the read-back of the counters.
     // (Capturing this fork / join into a hipGraph was tried: it replays correctly -- as long as stream3 does not rejoin
     // through stream2, which crashes hipStreamEndCapture on ROCm 7.2 -- but a graph launch is no faster than the ~35 plain
@@ -741,7 +784,7 @@ int enqueue_body(siftmi_plan *p) {
 int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     HIPCHK(hipSetDevice(p->device));
     // wait by polling: a blocking hipStreamSynchronize can add wake-up latency to a ~1 ms call
-    static const bool spin = getenv("SIFTMI_NO_SPIN") == nullptr;
+    const bool spin = p->opt.spin != 0;
     hipStream_t ws[2] = {p->wait_a ? p->wait_a : p->stream, p->wait_b};
     for (hipStream_t w : ws) {
         if (!w) continue;
@@ -761,7 +804,8 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
     }
     int64_t n = hc.n_out;
-    int ovf = hc.overflow;
+    // the overflow flag may have been raised by either detection stream after the other took its snapshot
+    int ovf = hc.overflow | p->hb->c.overflow | (p->wait_b ? p->hb->c2.overflow : 0);
     if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
     p->last_count = n;
     p->last_group0 = hc.grp_out_end[0] - hc.grp_out_start[0];
@@ -906,6 +950,7 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     siftmi_plan *p = b->lanes[l];
     const int img = b->lane_image[l];
     if (img < 0) return SIFTMI_OK;
+    if (img >= b->batch_size) { b->lane_image[l] = -1; return fail(SIFTMI_EINVAL, "stale frame index %d on lane %zu", img, l); }
     int64_t n = 0; int32_t ovf = 0;
     int rc = plan_wait(p, &n, &ovf);
     if (rc) return rc;
@@ -954,6 +999,21 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     b->lane_image[l] = -1;
     return SIFTMI_OK;
 }
+
+// Forget whatever is still in flight on the lanes (an earlier call that ended with an error): wait for each lane's
+// streams, ignore the results, mark every lane idle.  Without this the next call would retire stale image indices
+// into arrays sized for ITS batch.
+void batch_drain(siftmi_batch *b) {
+    for (size_t l = 0; l < b->lanes.size(); l++) {
+        if (b->lane_image[l] < 0) continue;
+        siftmi_plan *p = b->lanes[l];
+        if (hipSetDevice(p->device) == hipSuccess) {
+            for (hipStream_t s : {p->stream, p->stream2, p->stream3})
+                if (s) (void)hipStreamSynchronize(s);
+        }
+        b->lane_image[l] = -1;
+    }
+}
 }  // namespace
 extern "C" {
 
@@ -964,6 +1024,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     if (n_images < 0) return fail(SIFTMI_EINVAL, "negative image count");
     if ((host_outs == nullptr) != (host_caps == nullptr)) return fail(SIFTMI_EINVAL, "host_outs and host_caps go together");
     HIPCHK(hipSetDevice(b->device));
+    batch_drain(b);                      // no-op unless the previous call failed half way
     if (overflow) *overflow = 0;
     *total_parked = 0;
     b->arena_used = 0;
@@ -984,7 +1045,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     }
     for (int i = n_images > (int)L ? n_images - (int)L : 0; i < n_images && !rc; i++) rc = batch_retire(b, (size_t)i % L, overflow);
     b->host_outs = nullptr; b->host_caps = nullptr;
-    if (rc) return rc;
+    if (rc) { std::string keep = g_err; batch_drain(b); g_err = keep; return rc; }
     HIPCHK(hipDeviceSynchronize());                            // the parking copies
     for (int i = 0; i < n_images; i++) { counts[i] = b->counts[(size_t)i]; offsets[i] = b->offsets[(size_t)i]; }
     *total_parked = (int64_t)(b->arena_used / sizeof(KpRecord));
@@ -1418,7 +1479,7 @@ int siftmi_stage_blur(int32_t dev, const float *in, float *out, int32_t W, int32
     for (int i = 0; i < ntaps; i++) tp.t[i] = taps[i];
     if ((rc = dt.upload(tp.t, sizeof tp.t))) return rc;
     tp.dev = dt.as<float>();
-    if (!launch_blur_tiled<false>(0, a.as<float>(), b.as<float>(), W, H, tp, nullptr))
+    if (!launch_blur_tiled<false>(g_default_options, 0, a.as<float>(), b.as<float>(), W, H, tp, nullptr))
         launch_blur_generic(0, a.as<float>(), b.as<float>(), t.as<float>(), W, H, tp, nullptr, false);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(out, b.p, N * 4, hipMemcpyDeviceToHost));

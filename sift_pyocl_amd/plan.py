@@ -294,6 +294,11 @@ class SiftPlan(object):
 
     __call__ = keypoints
 
+    def set_option(self, name, value):
+        """Tuning / diagnostic option of the device plan by name (``siftmi_plan_set_option`` in include/siftmi.h);
+        results never depend on an option."""
+        _lib.check(_lib.lib().siftmi_plan_set_option(self._handle, str(name).encode(), int(value)))
+
     def device_records(self):
         """The records of the last keypoints() call where they lie on the device (no copy): an object with
         ``__cuda_array_interface__`` (uint8, n * 144 bytes), accepted by ``MatchPlan.match``.  Valid until the next

@@ -14,6 +14,9 @@ Fixtures (all inputs are regenerated from seeds by tests/util.py, only outputs a
   stages_131x97.npz   every intermediate of octaves 0 and 1 of a 131x97 smoothed-noise image
   kp_<name>.npz       final keypoints (sorted) of four synthetic images
   match.npz           match pairs of two 1500 / 1200 descriptor sets
+  kp_digests.json     per-field SHA-256 of the sorted keypoints of three large images (2048^2 smooth / white,
+                      1031x1537), produced by the reference kernels with their math builtins bound to siftmath
+                      (oracle/_ref/libsiftclref_sm.so: libm isolated -> the digests are reproducible bit for bit)
   transform.npz       affine warps (transform.cl) of a 97x131 float image and a 40x53 RGB image, cases of
                       tests/util.py:TRANSFORM_CASES
 """
@@ -28,7 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import pyref  # noqa: E402
-from util import TRANSFORM_CASES, transform_inputs, multiscale_noise, rectangles, smooth_noise, sort_kp, sort_rows, white_noise, dtype_kp  # noqa: E402
+from util import digest_cases, kp_digest, TRANSFORM_CASES, transform_inputs, multiscale_noise, rectangles, smooth_noise, sort_kp, sort_rows, white_noise, dtype_kp  # noqa: E402
 
 FINAL_CASES = {"white512": (white_noise, (512, 512)), "smooth512": (smooth_noise, (512, 512)),
                "multi300x421": (multiscale_noise, (300, 421)), "rect257x511": (rectangles, (257, 511))}
@@ -85,6 +88,15 @@ def main():
         out["rgb%d" % i] = pyref.transform(rgb, M, off, out_shape=oshape and tuple(s + e for s, e in zip(rgb.shape[:2], oshape)), fill=fill, mode=mode)
     np.savez_compressed(os.path.join(HERE, "transform.npz"), **out)
     print("transform cases", len(TRANSFORM_CASES))
+    import json
+    pyref.use("siftmath")
+    dig = {}
+    for name, (maker, shape, kw) in digest_cases().items():
+        dig[name] = kp_digest(pyref.keypoints(maker(shape, **kw)))
+        print(name, dig[name]["n"], "keypoints (digest)")
+    pyref.use("glibc")
+    with open(os.path.join(HERE, "kp_digests.json"), "w") as f:
+        json.dump(dig, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -56,3 +56,21 @@ def test_batch_2048_matches_single_plan(siftlib):
     again = keypoints_batch(frames[:3], lanes=2)
     for i in range(3):
         assert_same_keypoints(again[i], got[i], "keypoints_batch() helper")
+
+
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_batch_of_blank_frames(siftlib, lanes):
+    """A batch in which no frame has any keypoint (constant frames: the normalisation divides by zero, the reference does
+    not guard either) must come back as empty arrays -- in parked mode (lanes > 2) nothing is parked at all."""
+    import sift_pyocl_amd as sp
+    shape = (200, 260)
+    bp = sp.BatchPlan(shape=shape, dtype=np.float32, lanes=lanes)
+    blank = np.zeros(shape, np.float32)
+    got = bp.keypoints_batch([blank, blank + 3.0, blank])
+    assert [len(g) for g in got] == [0, 0, 0]
+    assert all(g.dtype == sp.SiftPlan.dtype_kp for g in got)
+    assert len(bp.keypoints(blank)) == 0
+    assert len(sp.SiftPlan(shape=shape, dtype=np.float32).keypoints(blank)) == 0
+    # and a mixed batch still delivers the non-empty frame
+    mixed = bp.keypoints_batch([blank, white_noise(shape, seed=3)])
+    assert len(mixed[0]) == 0 and len(mixed[1]) > 10

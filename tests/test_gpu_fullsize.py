@@ -7,8 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from util import (assert_same_keypoints, compare_keypoints_libm, multiscale_noise, rectangles, smooth_noise,
-                  sort_kp, sort_rows, white_noise)
+from util import (assert_same_keypoints, compare_keypoints_libm, digest_cases, kp_digest, multiscale_noise, rectangles,
+                  smooth_noise, sort_kp, sort_rows, white_noise)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -18,14 +18,27 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
                                               ("multi300x421", multiscale_noise, (300, 421)),
                                               ("rect257x511", rectangles, (257, 511))])
 def test_golden_final_keypoints(siftlib, name, maker, shape):
-    """HIP output against vectors produced by the reference's own kernels (glibc math): x, y exact,
-    scale/angle within 2 ulp, descriptor bins within 1 LSB in <= 1 % of rows (measured: 0 bins)."""
+    """HIP output against vectors produced by the reference's own kernels with glibc math: tolerance of
+    compare_keypoints_libm (on these four small images no descriptor bin differs at all)."""
     import sift_pyocl_amd as sp
     g = np.load(os.path.join(GOLD, "kp_%s.npz" % name))
     img = maker(shape)
     got = sp.SiftPlan(template=img).keypoints(img)
     stats = compare_keypoints_libm(got, g["kp"], name)
     assert stats["desc_bins_differing"] == 0
+
+
+@pytest.mark.parametrize("name", sorted(digest_cases()))
+def test_golden_digests_of_large_images(siftlib, name):
+    """HIP output == the reference's own kernels (math builtins bound to siftmath, oracle/_ref/libsiftclref_sm.so) on
+    2048 x 2048 / 1031 x 1537 frames, every byte of 39 k / 2.7 k / 18.7 k records, through committed per-field digests
+    (tests/golden/kp_digests.json, generator tests/golden/make_golden.py; needs neither the oracle nor the reference)."""
+    import json
+    import sift_pyocl_amd as sp
+    maker, shape, kw = digest_cases()[name]
+    img = maker(shape, **kw)
+    golden = json.load(open(os.path.join(GOLD, "kp_digests.json")))[name]
+    assert kp_digest(sp.SiftPlan(template=img).keypoints(img)) == golden
 
 
 def test_4096_white_noise_bit_exact(siftlib, oracle):

@@ -43,11 +43,9 @@ def test_integer_frames(siftlib, oracle, name, shape):
     mn, mx = plan.minmax()
     assert mn == ref32.min() and mx == ref32.max()
     # the convert-pass fallback gives the same bits
-    os.environ["SIFTMI_NO_FUSED_CONVERT"] = "1"
-    try:
-        assert_same_keypoints(sp.SiftPlan(template=img).keypoints(img), want, "%s frame, convert pass" % name)
-    finally:
-        del os.environ["SIFTMI_NO_FUSED_CONVERT"]
+    plain = sp.SiftPlan(template=img)
+    plain.set_option("fused_convert", 0)
+    assert_same_keypoints(plain.keypoints(img), want, "%s frame, convert pass" % name)
 
 
 @pytest.mark.parametrize("shape", [(180, 260), (520, 1030)])

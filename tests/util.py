@@ -65,25 +65,50 @@ def ulp_diff(a, b):
     return np.abs(a - b)
 
 
-def compare_keypoints_libm(a, b, what="", ulp=2, max_bad_rows=0.01):
-    """Comparison against the glibc-backed native build of the reference kernels.  x and y (pure
-    +,*,/ arithmetic) must be bit-identical; scale (pow) and angle (atan2/exp chain) may differ by
-    `ulp` units in the last place because glibc 2.35's powf/atan2f are not correctly rounded while
-    the oracle's are; descriptor bins may then differ by 1 LSB in at most `max_bad_rows` of the rows.
+def compare_keypoints_libm(a, b, what="", max_bad_rows=0.002, angle_abs=0.05, desc_lsb=10, scale_ulp=2):
+    """Comparison against the glibc-backed native build of the reference kernels (oracle/_ref/libsiftclref.so).
+
+    OpenCL leaves the last bits of exp / atan2 / pow to the implementation; the oracle's siftmath is correctly rounded
+    (within 2^-48 of a rounding boundary), glibc 2.35's atan2f / powf are not.  Measured at 2048 x 2048 / 1031 x 1537
+    (tests/test_oracle_vs_ref.py::test_glibc_build_tolerance, 60 k keypoints): count, x and y identical; scale within
+    2 ulp; angle and descriptor identical in > 99.9 % of the rows.  In the remaining rows a 1-ulp atan2 difference
+    moved one window sample across an orientation-bin edge (orientation_cpu.cl:88), which shifts the interpolated
+    angle by up to ~1.5e-2 rad and, through it, a few descriptor bins by a few LSB.  That is far inside what the
+    reference's own test accepts (test/test_keypoints.py: angle < 1e-1).  With the math builtins bound to siftmath
+    instead of glibc the reference kernels reproduce the oracle byte for byte (assert_same_keypoints).
     Returns a dict of the measured differences."""
     assert len(a) == len(b), "%s: %d vs %d keypoints" % (what, len(a), len(b))
     a, b = sort_kp(a), sort_kp(b)
     assert np.array_equal(a["x"].view(np.uint32), b["x"].view(np.uint32)), what + ": x differs"
     assert np.array_equal(a["y"].view(np.uint32), b["y"].view(np.uint32)), what + ": y differs"
     ds, da = ulp_diff(a["scale"], b["scale"]), ulp_diff(a["angle"], b["angle"])
-    assert ds.max(initial=0) <= ulp, "%s: scale differs by %d ulp" % (what, ds.max())
-    assert da.max(initial=0) <= ulp, "%s: angle differs by %d ulp" % (what, da.max())
+    assert ds.max(initial=0) <= scale_ulp, "%s: scale differs by %d ulp" % (what, ds.max())
+    dabs = np.abs(a["angle"].astype(np.float64) - b["angle"].astype(np.float64))
+    dabs = np.minimum(dabs, 2 * np.pi - dabs)
+    assert dabs.max(initial=0) <= angle_abs, "%s: angle differs by %g rad" % (what, dabs.max())
     dd = np.abs(a["desc"].astype(np.int16) - b["desc"].astype(np.int16))
-    assert dd.max(initial=0) <= 1, "%s: descriptor bins differ by %d" % (what, dd.max())
-    bad = int(((ds > 0) | (da > 0) | (dd.max(axis=1) > 0)).sum()) if len(a) else 0
+    assert dd.max(initial=0) <= desc_lsb, "%s: descriptor bins differ by %d" % (what, dd.max())
+    bad = int(((da > 2) | (dd.max(axis=1) > 0)).sum()) if len(a) else 0
     assert bad <= max(2, max_bad_rows * len(a)), "%s: %d of %d rows differ" % (what, bad, len(a))
     return dict(rows=len(a), rows_differing=bad, scale_ulp=int(ds.max(initial=0)), angle_ulp=int(da.max(initial=0)),
-                desc_bins_differing=int((dd > 0).sum()))
+                angle_rad=float(dabs.max(initial=0)), desc_bins_differing=int((dd > 0).sum()), desc_lsb=int(dd.max(initial=0)))
+
+
+def kp_digest(k):
+    """Per-field SHA-256 of a sorted keypoint set: lets a 2048^2 result (5.6 MB of records) be pinned by ~400 bytes."""
+    import hashlib
+    k = sort_kp(k)
+    out = {"n": int(len(k))}
+    for f in ("x", "y", "scale", "angle", "desc"):
+        out[f] = hashlib.sha256(np.ascontiguousarray(k[f]).tobytes()).hexdigest()
+    return out
+
+
+# name -> (maker, shape, kwargs): the large cases pinned by digest (tests/golden/kp_digests.json)
+def digest_cases():
+    return {"smooth2048": (smooth_noise, (2048, 2048), {}),
+            "white2048": (white_noise, (2048, 2048), {}),
+            "smooth1031x1537": (smooth_noise, (1031, 1537), dict(seed=9, sigma=2.0))}
 
 
 # (matrix[4], offset[2], fill, mode, extra (dy, dx) added to the output shape or None) -- transform.cl cases

@@ -35,10 +35,7 @@ def main():
         for mode in ("fused", "convert_pass"):
             if name == "float32" and mode == "convert_pass":
                 continue
-            if mode == "convert_pass":
-                os.environ["SIFTMI_NO_FUSED_CONVERT"] = "1"
-            else:
-                os.environ.pop("SIFTMI_NO_FUSED_CONVERT", None)
+            plan.set_option("fused_convert", 0 if mode == "convert_pass" else 1)
             for _ in range(3):
                 k = plan.keypoints(t)
             torch.cuda.synchronize()
@@ -48,7 +45,6 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.reps
             res[mode] = {"ms": round(1e3 * dt, 4), "Mpix_s": round(S * S / 1e6 / dt, 1), "keypoints": int(len(k))}
-        os.environ.pop("SIFTMI_NO_FUSED_CONVERT", None)
         out[name] = res
     print(json.dumps(out))
 

@@ -19,6 +19,9 @@ if dtype != "float32":
     img = ((img - img.min()) / (img.max() - img.min()) * np.iinfo(dtype).max).astype(dtype)
 t = torch.from_numpy(img).cuda()
 plan = sp.SiftPlan(shape=img.shape, dtype=img.dtype, profile=True, octave_max=octaves or None)
+for kv in sys.argv[5:]:                                        # name=value plan options (siftmi_plan_set_option)
+    name, value = kv.split("=")
+    plan.set_option(name, int(value))
 for _ in range(3):
     kp = plan.keypoints(t)
 print("image %s %dx%d octaves=%d -> %d keypoints" % (kind, size, size, plan.octave_max, len(kp)))

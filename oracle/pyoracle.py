@@ -64,6 +64,18 @@ def _f32(a):
 
 
 # ----------------------------------------------------------------------------- stages
+def expf_array(x):
+    x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+    lib().so_expf_array(_p(x), _p(out), C.c_int64(x.size))
+    return out
+
+
+def atan2f_array(y, x):
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+    lib().so_atan2f_array(_p(y), _p(x), _p(out), C.c_int64(x.size))
+    return out
+
+
 def gaussian_taps(sigma, size):
     out = np.empty(size, np.float32)
     lib().so_gaussian_taps(C.c_float(np.float32(sigma)), C.c_int(size), _p(out))

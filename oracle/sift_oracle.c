@@ -49,6 +49,15 @@ float so_expf(float x) { return om_expf(x); }
 float so_exp2f(float x) { return om_exp2f(x); }
 float so_atan2f(float y, float x) { return om_atan2f(y, x); }
 void so_sincosf(float x, float *s, float *c) { om_sincosf(x, s, c); }
+/* array forms (the device fast paths are checked on 10^7 arguments) */
+void so_expf_array(const float *x, float *out, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) out[i] = om_expf(x[i]);
+}
+void so_atan2f_array(const float *y, const float *x, float *out, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) out[i] = om_atan2f(y[i], x[i]);
+}
 
 /* ------------------------------------------------------------------ A3: Gaussian taps
  * gaussian.cl:56-140 launched with one work-group of nextpower(size) items

@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
 }
 
 // ------------------------------------------------------------------------------------------
-// Descriptor: ONE WAVEFRONT per oriented keypoint, no workgroup barriers (keypoints_cpu.cl:36-161).
+// Descriptor, streaming form: ONE WAVEFRONT per oriented keypoint, no workgroup barriers (keypoints_cpu.cl:36-161).
+// Handles windows of any size; since round 2 only used when a plan's windows can exceed SIFT_DESC_MAXRAD rows
+// (init_sigma > ~4) -- k_descriptor.hpp holds the row-interval form used otherwise.
 //
 //  1. The (2R+1)^2 raster scan is filtered to the samples that fall inside the rotated 5x5-cell
 //     window by an ORDER-PRESERVING compaction (wave ballot + popcount prefix) into a small LDS
@@ -277,7 +279,7 @@ struct DescWaveLds {
 };
 
 // 5 waves per SIMD (96 VGPRs, 20 bytes of scratch): +12 % on keypoint-dense frames against the natural 116 VGPRs / 4 waves
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void descriptor_stream_kernel(OctaveTable tab, const float4 *__restrict__ okp,
                                                          const int *__restrict__ oaux, const Counters *cnt, int group,
                                                          int range_start, int range_end,  // used when cnt == nullptr
                                                          int out_capacity, KpRecord *__restrict__ records) {
@@ -492,8 +494,11 @@ __global__ void gradient_kernel(const float *__restrict__ img, float *__restrict
     ori[(size_t)y * W + x] = o;
 }
 
-// elementwise siftmath (test hook)
+// elementwise siftmath (test hook); fn 5 / 6: the Ziv fast paths of exp / atan2
 __global__ void math_kernel(int fn, const float *__restrict__ a, const float *__restrict__ bb, float *__restrict__ out, int64_t n) {
+    __shared__ double fold[36];
+    siftmath::load_atan_fold(fold);
+    __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float s, c;
@@ -502,6 +507,9 @@ __global__ void math_kernel(int fn, const float *__restrict__ a, const float *__
             case 1: out[i] = siftmath::exp2f_(a[i]); break;
             case 2: siftmath::sincosf_(a[i], &s, &c); out[i] = s; break;
             case 3: siftmath::sincosf_(a[i], &s, &c); out[i] = c; break;
+            case 5: out[i] = siftmath::expf_fast(a[i]); break;
+            case 6: out[i] = siftmath::atan2f_fast(a[i], bb[i], fold); break;
+            case 7: out[i] = siftmath::div_by_reciprocal(a[i], bb[i], 1.0f / bb[i]); break;
             default: out[i] = siftmath::atan2f_(a[i], bb[i]); break;
         }
     }

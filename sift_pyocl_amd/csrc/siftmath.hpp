@@ -156,4 +156,109 @@ SM_HD float atan2f_(float yf, float xf) {
     return (float)res;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device fast paths (Ziv's strategy).  expf_ / atan2f_ above DEFINE the values: a fixed binary64 evaluation, rounded
+// once to binary32, which is the correctly rounded result unless the binary64 value lies within ~2^-48 (relative) of
+// a binary32 rounding boundary.  The functions below compute the same quantity with fewer, fused operations
+// (error <= 2^-45 relative, see the notes at each) and return its rounding only when the binary64 value is farther
+// than 2^-39 from every rounding boundary -- then both evaluations sit on the same side of the boundary and round to
+// the same binary32 number.  Otherwise (probability 2^-15 per call), and outside the guarded argument range, the
+// defining function is evaluated.  Results are therefore bit-identical to expf_ / atan2f_ for every argument
+// (checked on 10^7 arguments per function against the CPU oracle, tests/test_gpu_parity.py).
+#if defined(__HIPCC__)
+
+// T[swap + 2 * (x < 0)][k]: the octant fold applied to atan(k / 8), correctly rounded:
+//   {atan(k/8), pi/2 - atan(k/8), pi - atan(k/8), pi/2 + atan(k/8)};  atan2 = T -/+ atan(t) (minus for folds 1 and 2)
+__device__ const double c_atan_fold[36] = {
+    0x0.0p+0, 0x1.fd5ba9aac2f6ep-4, 0x1.f5b75f92c80ddp-3, 0x1.6f61941e4def1p-2, 0x1.dac670561bb4fp-2, 0x1.1e00babdefeb4p-1, 0x1.4978fa3269ee1p-1, 0x1.700a7c5784634p-1, 0x1.921fb54442d18p-1,
+    0x1.921fb54442d18p+0, 0x1.7249faa996a21p+0, 0x1.5368c951e9cfdp+0, 0x1.3647503caf55cp+0, 0x1.1b6e192ebbe44p+0, 0x1.031f57e54adbep+0, 0x1.dac670561bb4fp-1, 0x1.b434ee31013fdp-1, 0x1.921fb54442d18p-1,
+    0x1.921fb54442d18p+1, 0x1.8234d7f6ecb9dp+1, 0x1.72c43f4b1650ap+1, 0x1.643382c07913ap+1, 0x1.56c6e7397f5aep+1, 0x1.4a9f8694c6d6bp+1, 0x1.3fc176b7a8560p+1, 0x1.361d162e61b8bp+1, 0x1.2d97c7f3321d2p+1,
+    0x1.921fb54442d18p+0, 0x1.b1f56fdeef00fp+0, 0x1.d0d6a1369bd34p+0, 0x1.edf81a4bd64d4p+0, 0x1.0468a8ace4df6p+1, 0x1.109009519d639p+1, 0x1.1b6e192ebbe44p+1, 0x1.251279b802819p+1, 0x1.2d97c7f3321d2p+1};
+
+// every thread of the block copies the fold table into its LDS copy (36 doubles); the caller synchronises
+__device__ __forceinline__ void load_atan_fold(double *lds_tab) {
+    for (int i = threadIdx.x; i < 36; i += blockDim.x) lds_tab[i] = c_atan_fold[i];
+}
+
+// binary64 value (normal binary32 range) farther than 2^13 units of 2^-52 from the round-to-nearest boundary of binary32?
+__device__ __forceinline__ bool f32_rounding_is_safe(double v) {
+    const int low = (int)((unsigned)__double2loint(v) & 0x1fffffffu) - 0x10000000;   // 29 discarded bits vs the half-way pattern
+    return (low < 0 ? -low : low) > 8192;
+}
+
+// exp(x): one-step reduction x = k ln2 + r with a fused two-part ln2 (|r| <= 0.3466, reduction error < 2^-60),
+// Taylor degree 11 by fused Horner (truncation r^12/12! < 2^-47 relative), scaling by an exponent-field add.
+__device__ __forceinline__ float expf_fast(float xf) {
+    if (!(__builtin_fabsf(xf) <= 80.0f)) return expf_(xf);   // result outside the normal binary32 range, or NaN
+    const double x = (double)xf;
+    const double kd = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(-kd, 0x1.62e42fee00000p-1, x);
+    r = __builtin_fma(-kd, 0x1.a39ef35793c76p-33, r);
+    double p = 0x1.ae64567f544e4p-26;
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, r, 0x1.0p-1);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    // p in [0.70, 1.42], |k| <= 116: adding k to the exponent field is an exact scaling
+    const double v = __hiloint2double(__double2hiint(p) + (int)kd * (1 << 20), __double2loint(p));
+    if (!f32_rounding_is_safe(v)) return expf_(xf);
+    return (float)v;
+}
+
+// atan2(y, x) for finite non-zero arguments of comparable size (the gradient components of a window sample):
+// the same octant / table decomposition as atan2f_ with k taken from an approximate quotient (any k with
+// |num/den - k/8| <= 1/16 + 2^-20 serves), t = (num - c den) / (den + c num) by a Newton reciprocal (two steps from the
+// hardware seed: error < 2^-50), odd Taylor polynomial through t^11 (|t| <= 0.0626: truncation < 2^-51 relative), and
+// the three reflections of atan2f_ folded into one table value (c_atan_fold).  `fold` is the block's LDS copy.
+__device__ __forceinline__ float atan2f_fast(float yf, float xf, const double *fold) {
+    const float ay = __builtin_fabsf(yf), ax = __builtin_fabsf(xf);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    if (!(ax <= 1e18f && ay <= 1e18f && mn >= 1e-18f)) return atan2f_(yf, xf);   // zero / huge / NaN operands (fmin / fmax drop a NaN), or a sub-normal result
+    const bool swap = ay > ax;
+    const int k = (int)(mn * __builtin_amdgcn_rcpf(mx) * 8.0f + 0.5f);        // 0..8
+    const double c = (double)((float)k * 0.125f);
+    const double num = (double)mn, den = (double)mx;
+    const double tn = __builtin_fma(-c, den, num), td = __builtin_fma(c, num, den);
+    double r = __builtin_amdgcn_rcp(td);
+    r = __builtin_fma(__builtin_fma(-td, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-td, r, 1.0), r, r);
+    const double t = tn * r;
+    const double t2 = t * t;
+    double p = -0x1.745d1745d1746p-4;
+    p = __builtin_fma(p, t2, 0x1.c71c71c71c71cp-4);
+    p = __builtin_fma(p, t2, -0x1.2492492492492p-3);
+    p = __builtin_fma(p, t2, 0x1.999999999999ap-3);
+    p = __builtin_fma(p, t2, -0x1.5555555555555p-2);
+    const double at = __builtin_fma(t * t2, p, t);               // atan(t), same sign as t
+    const int f = (swap ? 1 : 0) + (__builtin_signbitf(xf) ? 2 : 0);
+    const double base = fold[f * 9 + k];
+    const double res = (f == 1 || f == 2) ? base - at : base + at;
+    if (!f32_rounding_is_safe(res)) return atan2f_(yf, xf);
+    const float out = (float)res;
+    return __builtin_signbitf(yf) ? -out : out;
+}
+
+// a / b correctly rounded, given rb = 1.0f / b correctly rounded (Markstein): q0 = RN(a rb) is within 2 ulp of a / b;
+// one residual step makes it faithful, the second one rounds correctly (Handbook of Floating-Point Arithmetic, 2nd ed.,
+// Theorem 4.9: y = RN(1/b), q faithful, r = a - b q exact  =>  RN(q + r y) = RN(a / b)).  Five dependent operations instead
+// of the 12-instruction IEEE sequence; valid without over / underflow, i.e. for the window coordinates below
+// (|a| <= 2^8, spacing in [0.1, 2^7]).  Checked against the IEEE division on 10^9 operand pairs (tests/test_gpu_parity.py).
+__device__ __forceinline__ float div_by_reciprocal(float a, float b, float rb) {
+    float q = a * rb;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, rb, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, rb, q);
+}
+
+#endif  // __HIPCC__
+
 }  // namespace siftmath

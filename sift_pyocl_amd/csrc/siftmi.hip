@@ -19,6 +19,7 @@
 #include "../../include/siftmi.h"
 #include "k_extrema.hpp"
 #include "k_keypoint.hpp"
+#include "k_descriptor.hpp"
 #include "k_align.hpp"
 #include "k_match.hpp"
 #include "k_pyramid.hpp"
@@ -93,7 +94,8 @@ struct Options {
     int march_wgs = 0;       // workgroups wanted by the one-block form (0: default)
     int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
     int ori_blocks = 1024, ori_pad = 0;
-    int desc_blocks = 2048, desc_pad = -1;   // -1: residency heuristic
+    int desc_blocks = 2048, desc_pad = -1;   // wave form of the descriptor kernel; -1: residency heuristic
+    int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
@@ -153,6 +155,7 @@ struct siftmi_plan {
     float4 *okp = nullptr;
     int *oaux = nullptr;
     KpRecord *records = nullptr;
+    bool desc_rows = true;        // descriptor windows fit the row tables of descriptor_kernel (R <= SIFT_DESC_MAXRAD for this init_sigma)
     Taps taps[6];                 // [0..4] per-octave schedule, [5] initial blur
     bool have_init = false;
     std::vector<Event> events;
@@ -179,6 +182,9 @@ int compute_schedule(siftmi_plan *p) {
     // plan.py:534-539 (initial blur) and plan.py:602-618 (per-octave increments)
     const double init_sigma = p->par.init_sigma;
     p->have_init = false;
+    // largest descriptor window: sigma <= init_sigma * 2^((3 + 1.5) / 3) (image.cl:354, |offset| <= 1.5), spacing = 3 sigma,
+    // R = (int)(1.414 * spacing * 2.5 + 0.5) (keypoints_cpu.cl:57-62); two rows of slack for float rounding
+    p->desc_rows = (int)(1.414 * 3.0 * init_sigma * std::pow(2.0, 1.5) * 2.5 + 0.5) + 2 <= SIFT_DESC_MAXRAD;
     if (init_sigma > 0.5) {   // par.DoubleImSize == 0 -> curSigma = 0.5
         const double s = std::sqrt(init_sigma * init_sigma - 0.25);
         p->taps[5].n = kernel_size(s);
@@ -423,8 +429,12 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         const int desc_pad_env = p->opt.desc_pad;
         int desc_pad = (group == 0 && p->overlap && p->n_oct > 1 && p->last_group0 <= 20000) ? 20000 : 0;
         if (desc_pad_env >= 0) desc_pad = desc_pad_env;
-        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                           (const float4 *)p->okp, (const int *)p->oaux, p->cnt, group, 0, 0, kcap, p->records);
+        if (p->desc_rows && !p->opt.desc_stream)
+            hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records);
+        else
+            hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records);
     }
 }
 
@@ -602,6 +612,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "ori_pad") o.ori_pad = v > 0 ? v : 0;
     else if (n == "desc_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_blocks must be >= 1"); o.desc_blocks = v; }
     else if (n == "desc_pad") o.desc_pad = v;
+    else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
@@ -1616,9 +1627,20 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
     for (int64_t i = 0; i < n; i++) aux[(size_t)i] = kp_scale[i] | (oct << 8);
     if (n > 0) {
         HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 1, 2048)), dim3(256), 0, 0, tab,
-                           (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (Counters *)nullptr, 0, 0, (int)n,
-                           (int)n, r.as<KpRecord>());
+        // row-interval form unless a window is too large for its row tables (same expressions as the kernel: keypoints_cpu.cl:57-62)
+        bool block_ok = true;
+        for (int64_t i = 0; i < n; i++) {
+            const float spacing = kps[4 * i + 2] / (float)octsize * 3.0f;
+            if (!((int)((1.414f * spacing * 2.5f) + 0.5f) <= SIFT_DESC_MAXRAD)) block_ok = false;
+        }
+        if (block_ok)
+            hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
+                               (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
+                               (int)n, r.as<KpRecord>());
+        else
+            hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
+                               (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
+                               (int)n, r.as<KpRecord>());
     }
     if ((rc = stage_end())) return rc;
     std::vector<KpRecord> h((size_t)n);

@@ -58,6 +58,73 @@ def test_device_math_bit_exact(siftlib, oracle, fn):
     assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
 
 
+@pytest.mark.parametrize("fn", [5, 6])
+def test_device_fast_paths_equal_the_defining_functions(siftlib, oracle, fn):
+    """siftmath's Ziv fast paths (expf_fast, atan2f_fast: fused binary64 evaluation + rounding-safety test, fallback to
+    the defining function) against the oracle's expf / atan2f on 10^7 arguments each: pipeline-like ranges, wide
+    ranges, exact ties of the octant selection, zeros / infinities / NaN / sub-normal results."""
+    rng = np.random.default_rng(100 + fn)
+    n = 1 << 20
+    for rnd in range(10):
+        if fn == 5:
+            kind = rnd % 5
+            if kind == 0: a = -(rng.random(n) * 12).astype(np.float32)                       # window weights
+            elif kind == 1: a = (rng.random(n) * 240 - 120).astype(np.float32)              # incl. under / overflow
+            elif kind == 2: a = (rng.standard_normal(n) * 10.0 ** rng.integers(-8, 2, n)).astype(np.float32)
+            elif kind == 3: a = (np.round(rng.random(n) * 160 - 80) * np.float32(0.6931472)).astype(np.float32)   # near k ln2
+            else: a = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)            # any bit pattern
+            a[:10] = [0, -0.0, -1e-30, -88.5, -103.9, -104.5, 1.0, np.nan, np.inf, -np.inf]
+            b = a
+            want = oracle.expf_array(a)
+        else:
+            kind = rnd % 5
+            if kind == 0:                                                                     # gradients of a 0..255 image
+                a = (rng.standard_normal(n) * 20).astype(np.float32); b = (rng.standard_normal(n) * 20).astype(np.float32)
+            elif kind == 1:
+                a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+                b = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(np.float32)
+            elif kind == 2:                                                                   # ratios at the octant-table ties
+                b = (rng.random(n) * 100 + 0.01).astype(np.float32)
+                a = (b * ((rng.integers(0, 8, n) + 0.5) / 8.0) * (1 + rng.integers(-3, 4, n) * 2.0 ** -23)).astype(np.float32)
+                a *= rng.choice([-1, 1], n).astype(np.float32); b *= rng.choice([-1, 1], n).astype(np.float32)
+            elif kind == 3:                                                                   # |y| == |x|, tiny and huge ratios
+                b = (rng.standard_normal(n) * 50).astype(np.float32)
+                a = (b * rng.choice([1.0, -1.0, 1e-20, 1e20, 1e-30, 1e-37], n)).astype(np.float32)
+            else:
+                a = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+                b = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+            a[:8] = [0, -0.0, 0, 1, -1, 0, np.inf, np.nan]; b[:8] = [0, 0, -0.0, 0, 0, -1, 1, 1]
+            want = oracle.atan2f_array(a, b)
+        out = np.empty(n, np.float32)
+        assert siftlib.siftmi_stage_math(0, fn, _p(a), _p(b), _p(out), n) == 0
+        bad = np.nonzero(out.view(np.uint32) != want.view(np.uint32))[0]
+        bad = bad[~(np.isnan(out[bad]) & np.isnan(want[bad]))]          # NaN payloads are not part of the contract
+        assert bad.size == 0, (fn, rnd, a[bad[:4]], b[bad[:4]], out[bad[:4]], want[bad[:4]])
+
+
+def test_division_by_reciprocal_is_the_ieee_quotient(siftlib):
+    """siftmath::div_by_reciprocal (Markstein's two residual steps on a correctly rounded reciprocal) replaces the
+    two divisions per descriptor sample (keypoints_cpu.cl:64-65): it must return the correctly rounded quotient for the
+    operands that occur there -- |a| < 2^8 (window coordinates, incl. exact zeros and values that cancel to a few ulp),
+    b = spacing in [0.1, 128].  numpy's float32 division is the IEEE quotient."""
+    rng = np.random.default_rng(77)
+    n = 1 << 22
+    for rnd in range(24):
+        b = np.exp(rng.uniform(np.log(0.1), np.log(128.0), n)).astype(np.float32)
+        kind = rnd % 4
+        if kind == 0: a = (rng.standard_normal(n) * 40).astype(np.float32)
+        elif kind == 1: a = (rng.uniform(-250, 250, n)).astype(np.float32)
+        elif kind == 2: a = (b * rng.integers(-30, 31, n) * np.float32(0.25) * (1 + rng.integers(-4, 5, n) * 2.0 ** -23)).astype(np.float32)  # near ties
+        else: a = (rng.standard_normal(n) * 10.0 ** rng.integers(-7, 2, n)).astype(np.float32)
+        a[:3] = [0.0, -0.0, 1.0]
+        if rnd == 5: b = rng.integers(0x3dcccccd, 0x43000000, n).astype(np.uint32).view(np.float32)       # every spacing pattern class
+        out = np.empty(n, np.float32)
+        assert siftlib.siftmi_stage_math(0, 7, _p(a), _p(b), _p(out), n) == 0
+        want = a / b
+        bad = np.nonzero((out.view(np.uint32) != want.view(np.uint32)) & ~((out == 0) & (want == 0)))[0]   # the sign of a zero
+        assert bad.size == 0, (rnd, a[bad[:4]], b[bad[:4]], out[bad[:4]], want[bad[:4]])                 # quotient is lost (1.5f is added next)
+
+
 # ----------------------------------------------------------------------------- stages
 def test_gaussian_taps(siftlib, oracle):
     for sigma, size in [(1.5198684, 15), (1.2262735, 11), (1.5450078, 15), (1.9465878, 17), (2.452547, 21), (3.0900156, 27),

@@ -89,6 +89,16 @@ int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
  * "team", "march_nt", "march_wgs", "march_nb", "ori_blocks", "ori_pad", "desc_blocks", "desc_pad", "desc_stream", "mm_blocks", "spin",
  * "host_timing".  Unknown name -> SIFTMI_EINVAL. */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
+/* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from
+ * siftmi_host_alloc: the descriptor kernels write every record straight into it while they run (zero-copy over PCIe),
+ * so no device-to-host copy follows the last kernel (the reference copies keypoints and descriptors of every octave
+ * back with blocking reads, plan.py:541-567). */
+#define SIFTMI_OUT_HOST 0
+#define SIFTMI_OUT_DEVICE 1
+#define SIFTMI_OUT_PINNED 2
+/* pinned, device-writable host blocks from a size-bucketed pool (sizes round up to a power of two >= 64 KiB) */
+int siftmi_host_alloc(int64_t bytes, void **out);
+int siftmi_host_free(void *ptr);
 int siftmi_plan_keypoints(siftmi_plan *plan, const void *image, int32_t image_dtype, int32_t image_is_device,
                           siftmi_keypoint *out, int32_t out_is_device, int64_t capacity, int64_t *n_out,
                           int32_t *overflow);

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "siftmi_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "siftmi_plan_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "siftmi_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "siftmi_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "siftmi_host_free": (C.c_int, [C.c_void_p]),
     "siftmi_plan_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "siftmi_plan_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]),
@@ -131,6 +133,34 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+class PinnedBlock(object):
+    """A pinned host block from the library's pool, exposed to numpy through ``__array_interface__``; arrays created
+    with ``numpy.asarray(block)`` (and their views) keep it alive, the block returns to the pool when the last one dies."""
+
+    def __init__(self, nbytes):
+        ptr = C.c_void_p()
+        check(lib().siftmi_host_alloc(int(nbytes), C.byref(ptr)))
+        self.ptr = ptr.value
+        self.nbytes = int(nbytes)
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr and _lib is not None:
+            try:
+                _lib.siftmi_host_free(ptr)
+            except Exception:
+                pass
+
+
+def pinned_empty(count, dtype):
+    """numpy array of `count` records of `dtype` in pinned, device-writable host memory"""
+    import numpy
+    dtype = numpy.dtype(dtype)
+    block = PinnedBlock(max(1, count) * dtype.itemsize)
+    return numpy.asarray(block)[:count * dtype.itemsize].view(dtype)
 
 
 def last_error():

@@ -47,18 +47,6 @@ struct alignas(16) DescRowLds {
     short row_jlo[2 * SIFT_DESC_MAXRAD + 4];   // first in-window jj of every row
 };
 
-// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts, no LDS)
-__device__ __forceinline__ int wave_inclusive_scan(int x) {
-    int t = x;
-    t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);   // row_shr:1
-    t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);   // row_shr:2
-    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);   // row_shr:4
-    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);   // row_shr:8
-    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
-    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
-    return t;
-}
-
 // next representable float towards +inf (up) or -inf, x finite and non-zero
 __device__ __forceinline__ float f32_neighbour(float x, bool up) {
     const int b = __float_as_int(x);
@@ -123,7 +111,7 @@ __device__ __forceinline__ void descriptor_sample(const float *__restrict__ I, i
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
-                       int out_capacity, KpRecord *__restrict__ records) {
+                       int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity) {
     __shared__ DescRowLds lds_all[4];
     __shared__ double fold[36];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -143,9 +131,9 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
         const int scale = aux & 0xff, oct = aux >> 8;
         const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
         KpRecord *rec = records + i;
+        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
         if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
-            if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
-            reinterpret_cast<uint16_t *>(rec->desc)[lane] = 0;
+            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.V));
             continue;
         }
         const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
@@ -210,7 +198,7 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
             const int yy = irow + ii;
             int c = jhi - jlo + 1;
             if (r >= S || yy < 0 || yy >= H || c < 0) c = 0;
-            const int incl = wave_inclusive_scan(c);
+            const int incl = wave_prefix_incl(c);
             if (r < S) { L.row_start[r] = carry + incl - c; L.row_jlo[r] = (short)jlo; }
             carry += __builtin_amdgcn_readlane(incl, 63);
         }
@@ -256,7 +244,7 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
             const uint2 ia = L.mask[lane], ib = L.mask[lane + 64];
             const int cnta = __popc(ia.x) + __popc(ia.y), cntb = __popc(ib.x) + __popc(ib.y);
             const int pa = (cnta + 3) & ~3, pb = (cntb + 3) & ~3;
-            const int base_a = wave_inclusive_scan(pa + pb) - (pa + pb);
+            const int base_a = wave_prefix_incl(pa + pb) - (pa + pb);
             const int base_b = base_a + pa;
             L.mbase[lane] = (unsigned)base_a;
             L.mbase[lane + 64] = (unsigned)base_b;
@@ -333,9 +321,7 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
         // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see the oracle's note)
         const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
-        rec->desc[lane] = (uint8_t)min(255, i0);
-        rec->desc[lane + 64] = (uint8_t)min(255, i1);
-        if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
+        store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.V));
     }
 }
 

@@ -101,6 +101,23 @@ __global__ void begin_image_kernel(Counters *c) {
     if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
 }
 
+// The 144-byte record leaves the wave as 36 coalesced dwords (lanes 0-3: x, y, scale, angle; lanes 4-35: four descriptor
+// bytes each, packed through `bytes`, 128 bytes of the wave's LDS) -- to the device list and, when `host` is not null, also
+// straight into the caller's pinned result array (zero-copy over PCIe: no device-to-host copy after the last kernel).
+__device__ __forceinline__ void store_record(KpRecord *dev, KpRecord *host, const float4 kq, int b0, int b1, int lane,
+                                             unsigned char *bytes) {
+    bytes[lane] = (unsigned char)b0; bytes[lane + 64] = (unsigned char)b1;
+    __builtin_amdgcn_wave_barrier();
+    unsigned w = 0u;
+    if (lane < 4) w = __float_as_uint(lane == 0 ? kq.x : (lane == 1 ? kq.y : (lane == 2 ? kq.z : kq.w)));
+    else if (lane < 36) w = reinterpret_cast<const unsigned *>(bytes)[lane - 4];
+    if (lane < 36) {
+        reinterpret_cast<unsigned *>(dev)[lane] = w;
+        if (host) reinterpret_cast<unsigned *>(host)[lane] = w;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 #ifdef SIFT_ABLATE
 __device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/exp, 3 refill only
 #define ABL(x) (g_ablate == (x))
@@ -111,17 +128,47 @@ __device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/
 // ------------------------------------------------------------------------------------------
 // Orientation assignment: one wave per refined keypoint (orientation_cpu.cl:41-174).
 // Output goes straight to the image-wide oriented list (x, y, sigma*oct, angle) + detection scale.
+//
+// The reference adds the window samples into hist[bin] in raster order.  64 consecutive samples at a time, one per lane:
+// every voting lane sets its bit in its bin's 64-bit mask (LDS atomic OR, order independent); lane b < 36 owns hist[b]
+// and gets a 16-byte aligned segment of a small value pool from a wave prefix sum of the vote counts; every voter stores
+// its value at segment base + (number of lower lanes voting for the same bin); the owner adds its segment front to back
+// (ascending lane == raster order), four values per LDS read.  atan2 / exp: Ziv fast paths of siftmath.hpp.
+struct alignas(16) OriWaveLds {
+    float pool[64 + 36 * 3 + 4];   // 64 values, every bin's segment padded to a multiple of 4
+    uint2 mask[36];
+    unsigned mbase[36];
+};
+
+__device__ __forceinline__ int wave_prefix_incl(int x) {      // inclusive prefix sum over the 64 lanes (DPP, no LDS)
+    int t = x;
+    t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);   // row_shr:1
+    t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);   // row_shr:2
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);   // row_shr:4
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);   // row_shr:8
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return t;
+}
+
 __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float ori_sigma,
                                                           const float4 *__restrict__ kp,
                                                           const int *__restrict__ kp_aux, Counters *cnt, int group,
                                                           int kp_capacity, float4 *__restrict__ okp,
                                                           int *__restrict__ oaux, int out_capacity) {
+    __shared__ OriWaveLds lds_all[4];
+    __shared__ double fold[36];
     const int lane = threadIdx.x & 63;
+    OriWaveLds &L = lds_all[threadIdx.x >> 6];
+    siftmath::load_atan_fold(fold);
+    if (lane < 36) L.mask[lane] = make_uint2(0u, 0u);
+    __syncthreads();
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int n = min(cnt->n_kp, kp_capacity);
     const int first = cnt->grp_kp_start[group];
     if (threadIdx.x == 0 && blockIdx.x == 0 && cnt->n_kp > kp_capacity) cnt->overflow = 1;
+    const float4 *pool4 = reinterpret_cast<const float4 *>(L.pool);
     for (int i = first + wave; i < n; i += nwaves) {
         const float4 k = kp[i];          // (peak, row, col, sigma)
         const int aux = kp_aux[i];       // detection scale | octave << 8
@@ -160,41 +207,53 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             const GradTaps taps = ntaps;
             nvalid = locate(base + 64, nr, nc);
             if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);
-            int bin = -1;
+            int bin = 0;
             float val = 0.0f;
             if (valid) {
-                float gval, a;
-                gradient_eval(taps, gval, a);
+                float gx = taps.xa - taps.xb, gy = taps.ya - taps.yb;
+                if (taps.bx) gx = 2.0f * gx;
+                if (taps.by) gy = 2.0f * gy;
+                const float gval = sqrtf(gx * gx + gy * gy);
                 float dif = (float)r - k.y;
                 float distsq = dif * dif;
                 dif = (float)c - k.z;
                 distsq = distsq + dif * dif;
                 valid = (gval > 0.0f) && (distsq < lim);
                 if (valid) {
+                    const float a = siftmath::atan2f_fast(-gy, gx, fold);
                     bin = (int)(36.0f * (a + SM_PI_F + 0.001f) / (2.0f * SM_PI_F));
                     valid = (bin >= 0) && (bin <= 36);
-                    bin = min(bin, 35);
-                    val = siftmath::expf_(-distsq / two_s2) * gval;
+                    bin = min(max(bin, 0), 35);
+                    val = siftmath::expf_fast(-distsq / two_s2) * gval;
                 }
+                if (valid) atomicOr(reinterpret_cast<unsigned *>(L.mask) + 2 * bin + (lane >> 5), 1u << (lane & 31));
             }
-            // Ordered accumulation.  The reference adds the samples into hist[bin] in raster order = ascending lane
-            // here.  Lane b collects the 64-bit mask of the lanes that vote for bin b (36 ballots), then every owner
-            // walks ITS mask in ascending order, fetching each value with a lane-indexed read (ds_bpermute): the trip
-            // count is the largest number of votes for one bin, not the number of samples in the batch.
-            uint32_t mlo = 0u, mhi = 0u;
-            const int vbin = valid ? bin : -1;
-#pragma unroll
-            for (int b = 0; b < 36; b++) {
-                const uint64_t m = __ballot(vbin == b);
-                if (lane == b) { mlo = (uint32_t)m; mhi = (uint32_t)(m >> 32); }
+            __builtin_amdgcn_wave_barrier();
+            // owners: vote counts -> aligned pool segments
+            const uint2 mine = (lane < 36) ? L.mask[lane] : make_uint2(0u, 0u);
+            const int votes = __popc(mine.x) + __popc(mine.y);
+            const int padded = (votes + 3) & ~3;
+            const int seg = wave_prefix_incl(padded) - padded;
+            if (lane < 36) L.mbase[lane] = (unsigned)seg;
+            __builtin_amdgcn_wave_barrier();
+            // voters: value to segment base + rank among the voters of the same bin (mbcnt: set bits below this lane)
+            {
+                const uint2 mk = L.mask[bin];
+                const unsigned mb = L.mbase[bin];
+                const int pos = mb + __builtin_amdgcn_mbcnt_hi(mk.y, __builtin_amdgcn_mbcnt_lo(mk.x, 0u));
+                if (valid) L.pool[pos] = val;
             }
-            uint64_t mine = (uint64_t)mlo | ((uint64_t)mhi << 32);
-            while (__ballot(mine != 0)) {
-                const int l = mine ? (__ffsll((unsigned long long)mine) - 1) : lane;
-                const float sv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l << 2, __builtin_bit_cast(int, val)));
-                if (mine) h = h + sv;
-                mine &= mine - 1;
+            __builtin_amdgcn_wave_barrier();
+            // owners: ordered sum of the segment
+            for (int k0 = 0; k0 < padded; k0 += 4) {
+                const float4 v = pool4[(seg + k0) >> 2];
+                h = h + v.x;
+                h = h + ((k0 + 1 < votes) ? v.y : 0.0f);
+                h = h + ((k0 + 2 < votes) ? v.z : 0.0f);
+                h = h + ((k0 + 3 < votes) ? v.w : 0.0f);
             }
+            if (votes) L.mask[lane] = make_uint2(0u, 0u);
+            __builtin_amdgcn_wave_barrier();
         }
         // six passes of circular [1 1 1]/3 smoothing; hist[35] sees the already updated hist[0];
         // the division is by the double literal 3.0 (orientation_cpu.cl:101-109)
@@ -282,7 +341,8 @@ struct DescWaveLds {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void descriptor_stream_kernel(OctaveTable tab, const float4 *__restrict__ okp,
                                                          const int *__restrict__ oaux, const Counters *cnt, int group,
                                                          int range_start, int range_end,  // used when cnt == nullptr
-                                                         int out_capacity, KpRecord *__restrict__ records) {
+                                                         int out_capacity, KpRecord *__restrict__ records,
+                                                         KpRecord *host_records, int host_capacity) {
     __shared__ DescWaveLds lds_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescWaveLds &L = lds_all[wave];
@@ -300,9 +360,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const int scale = aux & 0xff, oct = aux >> 8;
         const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
         KpRecord *rec = records + i;
+        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
         if (!(kq.y >= 0.0f)) {
-            if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
-            reinterpret_cast<uint16_t *>(rec->desc)[lane] = 0;
+            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.V));
             continue;
         }
         const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
@@ -478,9 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see oracle note)
         const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
-        rec->desc[lane] = (uint8_t)min(255, i0);
-        rec->desc[lane + 64] = (uint8_t)min(255, i1);
-        if (lane == 0) *reinterpret_cast<float4 *>(rec) = kq;
+        store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.V));
     }
 }
 

@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -155,6 +157,8 @@ struct siftmi_plan {
     float4 *okp = nullptr;
     int *oaux = nullptr;
     KpRecord *records = nullptr;
+    KpRecord *host_out = nullptr; // pinned result array of the call being enqueued (zero-copy delivery), or null
+    int host_cap = 0;
     bool desc_rows = true;        // descriptor windows fit the row tables of descriptor_kernel (R <= SIFT_DESC_MAXRAD for this init_sigma)
     Taps taps[6];                 // [0..4] per-octave schedule, [5] initial blur
     bool have_init = false;
@@ -431,10 +435,10 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         if (desc_pad_env >= 0) desc_pad = desc_pad_env;
         if (p->desc_rows && !p->opt.desc_stream)
             hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records);
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records);
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
     }
 }
 
@@ -832,9 +836,16 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
                           int32_t out_is_device, int64_t capacity, int64_t *n_out, int32_t *overflow) {
     if (!p || !image || !n_out) return fail(SIFTMI_EINVAL, "null argument");
     if (capacity > 0 && !out) return fail(SIFTMI_EINVAL, "null output with capacity > 0");
+    if (out_is_device < 0 || out_is_device > SIFTMI_OUT_PINNED) return fail(SIFTMI_EINVAL, "out_is_device must be 0 (host), 1 (device) or 2 (pinned host)");
     *n_out = 0;
     if (overflow) *overflow = 0;
+    // Pinned host result array (siftmi_host_alloc): the descriptor kernels write every record to it as well (zero-copy over
+    // PCIe while they run), so nothing is left to copy once the last kernel has ended.
+    const bool pinned = out_is_device == SIFTMI_OUT_PINNED && out && capacity > 0;
+    p->host_out = pinned ? reinterpret_cast<KpRecord *>(out) : nullptr;
+    p->host_cap = pinned ? (int)(capacity < 0x7fffffff ? capacity : 0x7fffffff) : 0;
     int rc = plan_enqueue(p, image, image_dtype, image_is_device, true);
+    p->host_out = nullptr; p->host_cap = 0;
     if (rc) return rc;
     int64_t n = 0;
     int32_t ovf = 0;
@@ -844,7 +855,7 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         // count-only call: the records stay on the device until siftmi_plan_fetch()
     } else {
         if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "output capacity too small; result truncated"; }
-        if (n > 0) {
+        if (n > 0 && !pinned) {
             HIPCHK(hipMemcpyAsync(out, p->records, (size_t)n * sizeof(KpRecord),
                                   out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, fin));
             HIPCHK(hipStreamSynchronize(fin));
@@ -853,6 +864,61 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     *n_out = n;
     if (overflow) *overflow = ovf;
     return rc;
+}
+
+// ---- pinned host blocks for result arrays (size-bucketed pool: hipHostMalloc / hipHostFree cost 0.1-1 ms each)
+}  // extern "C"
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;                 // block -> bucket size
+    std::unordered_map<size_t, std::vector<void *>> spare;   // bucket size -> free blocks
+    static constexpr size_t kKeep = 8;                        // spare blocks kept per bucket
+};
+HostPool &host_pool() { static HostPool *hp = new HostPool(); return *hp; }   // leaked on purpose: no teardown order issues
+}  // namespace
+extern "C" {
+
+int siftmi_host_alloc(int64_t bytes, void **out) {
+    if (!out || bytes < 0) return fail(SIFTMI_EINVAL, "bad argument");
+    *out = nullptr;
+    size_t bucket = (size_t)1 << 16;
+    while (bucket < (size_t)bytes) bucket <<= 1;
+    HostPool &hp = host_pool();
+    {
+        std::lock_guard<std::mutex> g(hp.mu);
+        auto it = hp.spare.find(bucket);
+        if (it != hp.spare.end() && !it->second.empty()) {
+            void *q = it->second.back();
+            it->second.pop_back();
+            hp.live[q] = bucket;
+            *out = q;
+            return SIFTMI_OK;
+        }
+    }
+    void *q = nullptr;
+    hipError_t e = hipHostMalloc(&q, bucket, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipHostMalloc(%zu): %s", bucket, hipGetErrorString(e));
+    std::lock_guard<std::mutex> g(hp.mu);
+    hp.live[q] = bucket;
+    *out = q;
+    return SIFTMI_OK;
+}
+
+int siftmi_host_free(void *ptr) {
+    if (!ptr) return SIFTMI_OK;
+    HostPool &hp = host_pool();
+    {
+        std::lock_guard<std::mutex> g(hp.mu);
+        auto it = hp.live.find(ptr);
+        if (it == hp.live.end()) return fail(SIFTMI_EINVAL, "not a siftmi_host_alloc block");
+        const size_t bucket = it->second;
+        hp.live.erase(it);
+        std::vector<void *> &v = hp.spare[bucket];
+        if (v.size() < HostPool::kKeep) { v.push_back(ptr); return SIFTMI_OK; }
+    }
+    (void)hipHostFree(ptr);
+    return SIFTMI_OK;
 }
 
 int siftmi_plan_fetch(siftmi_plan *p, siftmi_keypoint *out, int32_t out_is_device, int64_t first, int64_t count) {
@@ -1636,11 +1702,11 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
         if (block_ok)
             hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>());
+                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>());
+                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0);
     }
     if ((rc = stage_end())) return rc;
     std::vector<KpRecord> h((size_t)n);

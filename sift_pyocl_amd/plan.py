@@ -154,6 +154,10 @@ class SiftPlan(object):
         self._par_key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
         self._create(L)
         self.overflow = False
+        #: results up to 8 MB come back as views of pinned host blocks written by the kernels themselves (no copy after
+        #: the last kernel); a block returns to the library's pool when the array is dropped.  Set False to get plain
+        #: numpy.empty arrays filled by a device-to-host copy (e.g. when thousands of results are kept alive).
+        self.pinned_results = True
         self._last_n = 0
         self.debug = []
 
@@ -263,7 +267,15 @@ class SiftPlan(object):
             # numpy.empty cost nothing), so the host does not come back to Python between the count and the copy.  If the
             # frame has more keypoints than guessed, the records are still on the device: fetch them into an exact array.
             cap = int(1.5 * self._last_n) + 256
-            if cap * 144 <= (8 << 20):
+            if cap * 144 <= (8 << 20) and self.pinned_results:
+                # pinned result array from the library's pool: the descriptor kernels write the records straight into
+                # it (SIFTMI_OUT_PINNED), nothing is copied after the last kernel; it is recycled when the caller drops it
+                output = _lib.pinned_empty(cap, self.dtype_kp)
+                rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, output.ctypes.data, 2, cap, C.byref(n), C.byref(ovf))
+                _lib.check(rc, allow=(_lib.ECAPACITY,))
+                count = n.value
+                exact = rc == _lib.ECAPACITY
+            elif cap * 144 <= (8 << 20):
                 output = numpy.empty(cap, dtype=self.dtype_kp)
                 rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, output.ctypes.data, 0, cap, C.byref(n), C.byref(ovf))
                 _lib.check(rc, allow=(_lib.ECAPACITY,))

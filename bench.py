@@ -1,31 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- SiftPlan.keypoints() throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4]
 
-A step = one SiftPlan.keypoints() over one 4096x4096 fp32 synthetic image (uniform white noise, the
-BASELINE.json input) that is already resident in HBM when the timed region starts; 3 octaves x 3
-scales (BASELINE.json configs[1]).  With N > 1 each rank (one process per GPU) processes its own
-images -- independent units, no data-path collective -- and the timed region ends with the one
-exchange step of the batched path, an RCCL all-gather of the keypoint records of the last step.
-Rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 starts N ranks itself (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI)
+unless it already runs under a launcher (WORLD_SIZE set, e.g. `python -m torch.distributed.run --nproc-per-node N
+--master-addr 127.0.0.1 bench.py --gpus N ...`).  Rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel family is the fused separable Gaussian blur (blur_march_kernel<N,NORM>,
-16 launches per image, 42.7 % of the GPU time in profiles/r01/rocprofv3_summary.txt).  Its algorithmic traffic is
-1 read + 1 write of the plane = 8 B per pixel per launch ("5 chained blurs: 5R + 5W"); achieved =
-6 * 8 * W*H / (hipEvent time around the six full-resolution launches of an image: initial blur + the five scales
-of octave 0), measured live with HIP events on the plan's own pyramid stream; those launches run alone on the GPU,
-the later octaves' launches overlap the detection streams and cannot be timed in isolation.
-roofline_pipeline uses the whole-call model bytes_alg = W*H*(12 + 66*sum_o 4^-o) + 144 B/keypoint
-over the hipEvent time of all kernels of a call.
+config c2 (default, BASELINE.json configs[1]): a step = one SiftPlan.keypoints() over one 4096x4096 fp32 synthetic image
+(uniform white noise) that is already resident in HBM when the timed region starts; 3 octaves x 3 scales.  With N > 1
+each rank processes its own images -- independent units, no data-path collective ("weak" scaling) -- and the timed
+region ends with the one exchange step of the batched path: an all-gather of the keypoint records of the last step,
+from device memory (no host staging).
 
-cpu_baseline: the CPU oracle (a port of the reference's OpenCL-CPU kernels, OpenMP over all host
-cores) timed on rank 0 on the same workload -- a reported baseline, not the target.
+config c4 (BASELINE.json configs[3]): a step = one batch of 64 frames of 2048x2048 fp32, frame i owned by rank i mod N,
+each rank's share pipelined through a BatchPlan, then the all-gather of EVERY frame's records on device tensors.  The
+total work is fixed ("strong" scaling).
+
+roofline: the dominant kernel family is the fused separable Gaussian blur (blur_team_kernel<N, NORM, S>).  Algorithmic
+traffic = 1 read + 1 write of the plane = 8 B per pixel per launch; achieved = 6 * 8 * W*H / (hipEvent time
+around the six full-resolution launches of an image: initial blur + the five scales of octave 0), measured live with
+HIP events on the plan's own pyramid stream; those launches run alone on the GPU (the later octaves' launches overlap
+the detection streams and cannot be timed in isolation).  roofline_pipeline is the whole-call figure of SURVEY 8d:
+bytes_alg = W*H*(12 + 66*sum_o 4^-o) + 144 B/keypoint over the hipEvent time of all kernels of a call.
+
+cpu_baseline: the CPU oracle (a port of the reference's OpenCL-CPU kernels, OpenMP over all host cores) timed on rank 0
+on the same workload, and the reference's own kernels (built natively, one thread) -- reported baselines, not targets.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +43,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SIZE = 4096
 OCTAVES = 3
+C4_FRAMES, C4_SIZE = 64, 2048
 
 
 def make_image(seed, size=SIZE):
@@ -45,6 +52,15 @@ def make_image(seed, size=SIZE):
 
 def bytes_alg(w, h, n_oct, n_kp):
     return w * h * (12.0 + 66.0 * sum(4.0 ** -o for o in range(n_oct))) + 144.0 * n_kp
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [line.split(":", 1)[1].strip() for line in f if line.startswith("model name")]
+        return "%s (%d logical cpus)" % (names[0], len(names)) if names else "unknown"
+    except Exception:
+        return "unknown"
 
 
 def cpu_baseline(size, octaves):
@@ -66,15 +82,15 @@ def cpu_baseline(size, octaves):
         if el > 10.0 or reps >= 16:
             break
     mpix = reps * size * size / 1e6 / el
-    return {"value": round(mpix, 3), "unit": "Mpix/s", "cores": threads, "kind": "port",
+    return {"value": round(mpix, 3), "unit": "Mpix/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
             "keypoints_per_s": round(reps * nkp / el, 1),
             "sample": "%d x SiftPlan-equivalent pass over one %dx%d fp32 white-noise image, %d octaves, "
                       "oracle/sift_oracle.c with OpenMP on %d threads (%.1f s wall)" % (reps, size, size, octaves, threads, el)}
 
 
-def cpu_reference_kernels(octaves, size=1024):
+def cpu_reference_kernels(size, octaves):
     """The reference's OWN OpenCL-CPU kernels, compiled natively into oracle/_ref (when that build travelled with the
-    snapshot), driven serially on one host thread over a bounded sample.  None if the library is absent."""
+    snapshot), driven serially on one host thread over ONE pass of the same frame.  None if the library is absent."""
     try:
         from oracle import pyref
         if not pyref.available():
@@ -82,19 +98,110 @@ def cpu_reference_kernels(octaves, size=1024):
         img = make_image(0, size)
         pyref.keypoints(make_image(1, 256), octave_max=octaves)
         t0 = time.perf_counter()
-        reps = 0
-        while True:
-            k = pyref.keypoints(img, octave_max=octaves)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > 4.0 or reps >= 4:
-                break
-        return {"value": round(reps * size * size / 1e6 / el, 3), "unit": "Mpix/s", "cores": 1, "kind": "reference",
-                "keypoints_per_s": round(reps * len(k) / el, 1),
-                "sample": "%d x the reference's own kernels (openCL/*.cl built natively, oracle/_ref) over one %dx%d fp32 "
-                          "white-noise image, %d octaves, serial NDRange on 1 thread (%.1f s wall)" % (reps, size, size, octaves, el)}
+        k = pyref.keypoints(img, octave_max=octaves)
+        el = time.perf_counter() - t0
+        return {"value": round(size * size / 1e6 / el, 3), "unit": "Mpix/s", "cores": 1, "kind": "reference",
+                "keypoints_per_s": round(len(k) / el, 1),
+                "sample": "1 pass of the reference's own kernels (openCL/*.cl built natively, oracle/_ref) over one %dx%d fp32 "
+                          "white-noise image, %d octaves, serial NDRange on 1 thread (%.1f s wall)" % (size, size, octaves, el)}
     except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
         return {"error": str(exc)[:200]}
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start N copies of this script, one per GPU, and wait for them."""
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    if args.gpus > visible and not args.share_gpu:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --share-gpu to rehearse the N>1 path on one GPU)"
+                         % (args.gpus, visible))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")     # as torch.distributed.run does: N ranks must not each spin on every core
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    raise SystemExit(rc)
+
+
+def extras(sp, torch, size, n_oct, local_rank):
+    """Measurements beside the headline, N = 1 only, outside the timed region and never part of `value`."""
+    out = {}
+    # (1) the pipelined path (BatchPlan, SURVEY 8f-4): what a caller with a stack of frames gets from one GPU
+    try:
+        frames = [torch.from_numpy(make_image(i, size)).cuda() for i in range(8)] * 2
+        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct, lanes=2)
+        bp.keypoints_batch(frames)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(4):
+            t1 = time.perf_counter()
+            res = bp.keypoints_batch(frames)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+        tb = sorted(times)[len(times) // 2]
+        out["pipelined"] = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s",
+                            "ms_per_frame": round(1e3 * tb / len(frames), 4), "frames_per_call": len(frames), "lanes": 2,
+                            "keypoints": int(sum(len(r) for r in res)),
+                            "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans; every frame bit-identical "
+                                    "to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
+        del bp, frames
+    except Exception as exc:
+        out["pipelined"] = {"error": str(exc)[:200]}
+    # (2) host-to-host: the reference API takes host numpy arrays (plan.py:450-456); PCIe-inclusive, never `value`
+    try:
+        plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct)
+        host = make_image(3, size)
+        pinned = torch.from_numpy(host).pin_memory().numpy()
+        res = {}
+        for name, img in (("pageable", host), ("pinned", pinned)):
+            for _ in range(2):
+                plan.keypoints(img)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                plan.keypoints(img)
+            res[name] = (time.perf_counter() - t1) / 5
+        out["host_to_host"] = {"ms_per_image_pageable_input": round(1e3 * res["pageable"], 4),
+                               "ms_per_image_pinned_input": round(1e3 * res["pinned"], 4),
+                               "value": round(size * size / 1e6 / res["pinned"], 2), "unit": "Mpix/s",
+                               "note": "numpy image in, numpy recarray out: 64 MiB H->D over PCIe Gen5 x16 inside the call"}
+        del plan
+    except Exception as exc:
+        out["host_to_host"] = {"error": str(exc)[:200]}
+    # (3) MatchPlan, BASELINE.json configs[4]: 100k x 100k 128-D uint8 descriptors, L1 + ratio test as the reference
+    try:
+        n = 100000
+        rng = np.random.default_rng(1)
+        a = np.zeros(n, sp.MatchPlan.dtype_kp); a["desc"] = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        b = np.zeros(n, sp.MatchPlan.dtype_kp)
+        perm = rng.permutation(n); half = n // 2
+        b["desc"][:half] = np.clip(a["desc"][perm[:half]].astype(np.int16) + rng.integers(-8, 9, (half, 128)), 0, 255).astype(np.uint8)
+        b["desc"][half:] = rng.integers(0, 256, (n - half, 128), dtype=np.uint8)
+        mp = sp.MatchPlan(size=n, device=local_rank)
+        ta = torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda(); tb_ = torch.from_numpy(b.view(np.uint8).reshape(-1)).cuda()
+        torch.cuda.synchronize()
+        mp.match(ta, tb_, raw_results=True)
+        t1 = time.perf_counter()
+        pairs = mp.match(ta, tb_, raw_results=True)
+        el = time.perf_counter() - t1
+        ms = mp.kernel_ms()
+        out["match_100k"] = {"kernel_ms": round(ms, 3), "call_ms_device_lists": round(1e3 * el, 3), "pairs": int(len(pairs)),
+                             "expected_pairs": half, "descriptor_pairs_per_s": round(float(n) * n / (ms / 1e3), 1),
+                             "byte_sad_per_s": round(float(n) * n * 128 / (ms / 1e3), 1),
+                             "note": "brute-force L1 + 0.73^2 ratio test, both lists resident in HBM"}
+    except Exception as exc:
+        out["match_100k"] = {"error": str(exc)[:200]}
+    return out
 
 
 def main():
@@ -102,14 +209,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=SIZE, help="image side (default: the BASELINE config, 4096)")
-    ap.add_argument("--octaves", type=int, default=OCTAVES, help="0 = every octave (reference default)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2: one 4096^2 frame per step and GPU (default, the headline); c4: 64 x 2048^2 frames sharded over the GPUs")
+    ap.add_argument("--size", type=int, default=0, help="image side (default: the BASELINE config: 4096 for c2, 2048 for c4)")
+    ap.add_argument("--octaves", type=int, default=-1, help="0 = every octave (reference default); default 3 for c2, all for c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra BatchPlan measurement")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 "
-                                                      "code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-pipelined", "--no-extras", dest="no_extras", action="store_true",
+                    help="skip the extra measurements (BatchPlan, host-to-host, MatchPlan)")
+    ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo only with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -123,152 +235,173 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
-    # collectives run on device tensors with RCCL; the gloo rehearsal stages them through the host
-    xdev = "cuda" if args.backend == "nccl" else "cpu"
+    # RCCL refuses two ranks on one device, so the one-GPU rehearsal of the N>1 path runs its collectives over gloo
+    backend = args.backend or ("gloo" if args.share_gpu else "nccl")
+    xdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=backend)
+        world_observed = dist.get_world_size()
+    else:
+        world_observed = 1
 
     import sift_pyocl_amd as sp
-    from sift_pyocl_amd.batch import RECORD_BYTES
+    from sift_pyocl_amd.batch import RECORD_BYTES, gather_records_device, shard_indices
 
-    size, K, W = args.size, args.steps, args.warmup
-    plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, devicetype="GPU", device=local_rank, profile="light",
-                       octave_max=args.octaves or None)
-    n_oct = plan.octave_max
-    # inputs resident in HBM before the timed region (distinct images, seeds as SURVEY 8d)
-    n_img = min(max(K, 1), 8)
-    dev_images = [torch.from_numpy(make_image(rank * 1000 + i, size)).cuda() for i in range(n_img)]
-    torch.cuda.synchronize()
+    c4 = args.config == "c4"
+    size = args.size or (C4_SIZE if c4 else SIZE)
+    octaves = args.octaves if args.octaves >= 0 else (0 if c4 else OCTAVES)
+    K, W = args.steps, args.warmup
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    last = None
-    for i in range(W):
-        last = plan.keypoints(dev_images[i % n_img])
-    if distributed:   # warm the collective path too
-        t = torch.zeros(8, dtype=torch.uint8, device=xdev)
-        o = torch.empty(8 * world, dtype=torch.uint8, device=xdev)
-        dist.all_gather_into_tensor(o, t)
+    def xfer(t):           # device tensor -> the collective's device (identity for nccl)
+        return t if t.device == xdev else t.to(xdev)
 
-    blur_ms = blur_px = tot_ms = 0.0
-    blur_launches = 0
-    b0_ms = b0_px = 0.0
-    b0_launches = 0
-    n_kp = 0
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(K):
-        last = plan.keypoints(dev_images[i % n_img])
-        n_kp += len(last)
-        kt = plan.kernel_times()
-        blur_ms += kt["blur_ms"]; blur_px += kt["blur_pixels"]; blur_launches += kt["blur_launches"]
-        tot_ms += kt["total_ms"]
-        b0_ms += kt["blur0_ms"]; b0_px += kt["blur0_pixels"]; b0_launches += kt["blur0_launches"]
-    if distributed:
-        # the batched path's single exchange step: all-gather of the keypoint records (padded)
-        cnt = torch.tensor([len(last)], dtype=torch.int64, device=xdev)
-        cnts = torch.empty(world, dtype=torch.int64, device=xdev)
-        dist.all_gather_into_tensor(cnts, cnt)
-        mx = int(cnts.max().item())
-        buf = torch.zeros(max(1, mx) * RECORD_BYTES, dtype=torch.uint8, device=xdev)
-        raw = torch.from_numpy(np.ascontiguousarray(last).view(np.uint8).reshape(-1).copy())
-        buf[:raw.numel()] = raw.to(xdev)
-        allbuf = torch.empty(world * buf.numel(), dtype=torch.uint8, device=xdev)
-        dist.all_gather_into_tensor(allbuf, buf)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    result = {}
+    if c4:
+        # ---------------------------------------------------------------- C4: 64 x 2048^2 sharded over the ranks
+        mine = shard_indices(C4_FRAMES, rank, world)
+        frames = [torch.from_numpy(make_image(1000 + i, size)).cuda() for i in mine]
+        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=octaves or None)
+        n_oct = bp.octave_max
+        torch.cuda.synchronize()
+
+        def step():
+            counts, records = bp.keypoints_batch_device(frames)
+            if distributed:
+                all_counts, gathered = gather_records_device(counts, xfer(records), C4_FRAMES, rank, world)
+                return sum(sum(r) for r in all_counts), gathered
+            return sum(counts), records
+
+        for _ in range(max(W, 1)):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        total_kp = 0
+        for _ in range(K):
+            nk, keep = step()
+            total_kp += nk
+        barrier()
+        elapsed = time.perf_counter() - t0
+        units = K * C4_FRAMES * size * size / 1e6
+        workload = ("batch of %d frames of %dx%d fp32 uniform white noise, frame i on rank i mod %d (%d per GPU), BatchPlan "
+                    "(%d lanes) per rank, frames resident in HBM, all-gather of every frame's records on device tensors"
+                    % (C4_FRAMES, size, size, world, len(mine), bp.lanes))
+        result.update(scaling="strong", images_per_step=C4_FRAMES, kp_per_img=total_kp / max(K, 1) / C4_FRAMES, n_oct=n_oct)
+        kt = None
+    else:
+        # ---------------------------------------------------------------- C2: one 4096^2 frame per step and GPU
+        plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, devicetype="GPU", device=local_rank, profile="light",
+                           octave_max=octaves or None)
+        n_oct = plan.octave_max
+        n_img = min(max(K, 1), 8)
+        dev_images = [torch.from_numpy(make_image(rank * 1000 + i, size)).cuda() for i in range(n_img)]
+        torch.cuda.synchronize()
+
+        def exchange():
+            """the batched path's single exchange step, here for the records of the last frame: device tensors in,
+            device tensor out (the records are still in the plan's HBM list: no host staging)"""
+            counts = [plan.device_records().count]
+            rec = torch.as_tensor(plan.device_records(), device=torch.device("cuda", local_rank))
+            return gather_records_device(counts, xfer(rec), world, rank, world)
+
+        for i in range(W):
+            plan.keypoints(dev_images[i % n_img])
+        if distributed:
+            exchange()
+        blur_ms = blur_px = tot_ms = b0_ms = b0_px = 0.0
+        b0_launches = 0
+        n_kp = 0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            last = plan.keypoints(dev_images[i % n_img])
+            n_kp += len(last)
+            t = plan.kernel_times()
+            blur_ms += t["blur_ms"]; blur_px += t["blur_pixels"]; tot_ms += t["total_ms"]
+            b0_ms += t["blur0_ms"]; b0_px += t["blur0_pixels"]; b0_launches += t["blur0_launches"]
+        if distributed:
+            exchange()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        total_kp = n_kp
+        units = world * K * size * size / 1e6
+        workload = ("SiftPlan %dx%d fp32 uniform white noise (numpy default_rng(seed).random), %d octaves x 3 scales, input "
+                    "resident in HBM, records returned to host" % (size, size, n_oct))
+        result.update(scaling="weak", images_per_step=world, kp_per_img=n_kp / max(K, 1), n_oct=n_oct)
+        kt = dict(b0_ms=b0_ms, b0_px=b0_px, b0_launches=b0_launches, tot_ms=tot_ms)
+
     if distributed:
         el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-        tk = torch.tensor([float(n_kp)], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
-        total_kp = float(tk.item())
-    else:
-        total_kp = float(n_kp)
+        if not c4:
+            tk = torch.tensor([float(total_kp)], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+            total_kp = float(tk.item())
 
-    # Extra, outside the timed region and never part of `value`: the pipelined path (BatchPlan) on the same
-    # frames -- what a caller with a stack of frames gets from one GPU (N = 1 only).
-    pipelined = None
-    if world == 1 and not args.no_pipelined:
-        try:
-            del plan
-            frames = [dev_images[i % n_img] for i in range(16)]
-            bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=args.octaves or None, lanes=2)
-            bp.keypoints_batch(frames)                      # warm-up: sizes the result arena
-            torch.cuda.synchronize()
-            times = []
-            for _ in range(4):
-                t1 = time.perf_counter()
-                res = bp.keypoints_batch(frames)
-                torch.cuda.synchronize()
-                times.append(time.perf_counter() - t1)
-            sys.stderr.write("[bench] pipelined call times (ms): %s\n" % ", ".join("%.2f" % (1e3 * t) for t in times))
-            tb = sorted(times)[len(times) // 2]
-            pipelined = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s", "ms_per_frame": round(1e3 * tb / len(frames), 4),
-                         "frames_per_call": len(frames), "lanes": 2, "keypoints": int(sum(len(r) for r in res)),
-                         "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans, one result copy; every frame "
-                                 "bit-identical to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
-            del bp
-        except Exception as exc:
-            pipelined = {"error": str(exc)[:200]}
+    extra = {}
+    if world == 1 and not args.no_extras and not c4:
+        del plan
+        extra = extras(sp, torch, size, n_oct, local_rank)
 
     if rank == 0:
-        mpix_total = world * K * size * size / 1e6
-        value = mpix_total / elapsed
-        blur_gbs = (8.0 * b0_px / 1e9) / (b0_ms / 1e3) if b0_ms > 0 else 0.0          # full-resolution launches
-        blur_all_gbs = (8.0 * blur_px / 1e9) / (blur_ms / 1e3) if blur_ms > 0 else 0.0
-        # HBM traffic per blur launch from the committed rocprofv3 PMC passes of this same command
-        # (FETCH_SIZE x2 + WRITE_SIZE, see tools/summarize_prof.py); null when absent or another config
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "blur_traffic.json")
-        if os.path.exists(tfile) and size == SIZE and n_oct == OCTAVES:
-            try:
-                traffic = round(json.load(open(tfile))["traffic_bytes_per_launch"], 1)
-            except Exception:
-                traffic = None
-        kp_per_img = n_kp / max(K, 1)
-        pipe_gbs = (bytes_alg(size, size, n_oct, kp_per_img) * K / 1e9) / (tot_ms / 1e3) if tot_ms > 0 else 0.0
         out = {
-            "metric": "SiftPlan.keypoints throughput, 4096x4096 fp32 (Mpix/s; keypoints/s in keypoints_per_s)",
-            "value": round(value, 2), "unit": "Mpix/s",
+            "metric": "SiftPlan.keypoints throughput, %dx%d fp32 (Mpix/s; keypoints/s in keypoints_per_s)" % (size, size),
+            "value": round(units / elapsed, 2), "unit": "Mpix/s",
             "keypoints_per_s": round(total_kp / elapsed, 1),
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / max(K, 1), 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": result["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SiftPlan %dx%d fp32 uniform white noise (numpy default_rng(seed).random), "
-                                   "%d octaves x 3 scales, input resident in HBM, records returned to host"
-                                   % (size, size, n_oct),
-                       "octaves": n_oct, "scales": 3, "keypoints_per_image": round(kp_per_img, 1),
-                       "images_per_gpu_per_step": 1, "exchange": "rccl all_gather of keypoint records" if distributed else "none"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "blur_march_kernel<N,NORM>, the %d full-resolution (octave 0) launches per image: initial "
-                                   "blur + 5 scales (79 %% of all blur bytes at 3 octaves); they never overlap another kernel, "
-                                   "later octaves run concurrently with the detection streams" % (b0_launches // max(K, 1)),
-                         "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(blur_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "avg_launch_us": round(1e3 * b0_ms / max(b0_launches, 1), 2),
-                         "alg_bytes_per_launch": round(8.0 * b0_px / max(b0_launches, 1), 1),
-                         "timing": "one hipEvent pair on the plan's pyramid stream around the 6 back-to-back launches "
-                                   "(inter-kernel gaps included)"},
-            "roofline_pipeline": {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
-                                  "kernel_ms_per_image": round(tot_ms / max(K, 1), 4),
-                                  "bytes_alg_per_image": bytes_alg(size, size, n_oct, kp_per_img)},
+            "config": {"workload": workload, "name": args.config, "octaves": result["n_oct"], "scales": 3,
+                       "keypoints_per_image": round(result["kp_per_img"], 1), "images_per_step": result["images_per_step"],
+                       "exchange": ("all_gather of keypoint records on device tensors, backend %s, world size %d as seen by "
+                                    "torch.distributed" % (backend, world_observed)) if distributed else "none",
+                       "backend": backend if distributed else None, "world_size_observed": world_observed},
         }
-        if pipelined is not None:
-            out["pipelined"] = pipelined
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(size, n_oct)
-            ref = cpu_reference_kernels(n_oct)
+        if kt is not None:
+            blur_gbs = (8.0 * kt["b0_px"] / 1e9) / (kt["b0_ms"] / 1e3) if kt["b0_ms"] > 0 else 0.0
+            # HBM traffic per full-resolution blur launch: not observable from inside this process -- replayed from the
+            # committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, tools/summarize_prof.py)
+            traffic, traffic_src = None, None
+            for rel in ("profiles/r02/blur_traffic.json", "profiles/blur_traffic.json"):
+                tfile = os.path.join(ROOT, rel)
+                if os.path.exists(tfile) and size == SIZE and result["n_oct"] == OCTAVES:
+                    try:
+                        traffic = round(json.load(open(tfile))["traffic_bytes_per_launch"], 1)
+                        traffic_src = "replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % rel
+                        break
+                    except Exception:
+                        traffic = None
+            pipe_gbs = (bytes_alg(size, size, result["n_oct"], result["kp_per_img"]) * K / 1e9) / (kt["tot_ms"] / 1e3) if kt["tot_ms"] > 0 else 0.0
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "blur_team_kernel<N, NORM, S> (fused separable Gaussian blur): the %d full-resolution (octave 0) "
+                          "launches per image, initial blur + 5 scales (79 %% of all blur bytes at 3 octaves); they never "
+                          "overlap another kernel, later octaves run concurrently with the detection streams"
+                          % (kt["b0_launches"] // max(K, 1)),
+                "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(blur_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": round(1e3 * kt["b0_ms"] / max(kt["b0_launches"], 1), 2),
+                "alg_bytes_per_launch": round(8.0 * kt["b0_px"] / max(kt["b0_launches"], 1), 1),
+                "timing": "one hipEvent pair on the plan's pyramid stream around the 6 back-to-back launches "
+                          "(inter-kernel gaps included)"}
+            out["roofline_pipeline"] = {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
+                                        "kernel_ms_per_image": round(kt["tot_ms"] / max(K, 1), 4),
+                                        "bytes_alg_per_image": bytes_alg(size, size, result["n_oct"], result["kp_per_img"])}
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1 and not c4:
+            out["cpu_baseline"] = cpu_baseline(size, result["n_oct"])
+            ref = cpu_reference_kernels(size, result["n_oct"])
             if ref is not None:
                 out["cpu_baseline_reference_kernels"] = ref
         print(json.dumps(out), flush=True)

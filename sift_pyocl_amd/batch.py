@@ -61,6 +61,48 @@ class BatchPlan(SiftPlan):
         _lib.check(_lib.lib().siftmi_batch_blur_ms(self._handle, C.byref(ms), C.byref(nl), C.byref(px)))
         return {"blur0_ms": ms.value, "blur0_launches": nl.value, "blur0_pixels": px.value}
 
+    def _sync_params(self, L):
+        """`par` is read at call time, as in the reference"""
+        key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
+        if key != self._par_key:
+            params = self._current_params()
+            _lib.check(L.siftmi_batch_set_params(self._handle, C.byref(params)))
+            self._params, self._par_key = params, key
+
+    def _marshal(self, images):
+        """pointer table, element-type code, residency flag and keep-alive list of a batch of frames"""
+        n = len(images)
+        ptrs = (C.c_void_p * n)()
+        keep = []
+        dev_flags = set()
+        code = None
+        for i, image in enumerate(images):
+            ptr, is_dev, dtype, shape, k = _pointer_of(image)
+            assert tuple(shape[:2]) == tuple(self.shape)
+            assert dtype in [self.dtype, numpy.float32]
+            if dtype == numpy.float32 and len(shape) == 2:
+                c = _lib.DTYPE_CODES["float32"]
+            elif self.dtype == numpy.float64 and dtype == numpy.float64:
+                k = k.float() if is_dev else k.astype(numpy.float32)
+                ptr = k.data_ptr() if is_dev else k.ctypes.data
+                c = _lib.DTYPE_CODES["float32"]
+            elif len(shape) == 3 and dtype == numpy.uint8 and self.RGB:
+                c = _lib.DTYPE_CODES["rgb8"]
+            elif self.dtype in self.converter and len(shape) == 2:
+                c = _lib.DTYPE_CODES[self.dtype.name]
+            else:
+                raise RuntimeError("invalid input format error (%s)" % (str(self.dtype)))
+            if code is None:
+                code = c
+            elif c != code:
+                raise RuntimeError("all frames of a batch must have the same element type")
+            ptrs[i] = ptr
+            keep.append(k)
+            dev_flags.add(int(bool(is_dev)))
+        if len(dev_flags) != 1:
+            raise RuntimeError("the frames of a batch must be all host arrays or all device tensors")
+        return ptrs, code, dev_flags.pop(), keep
+
     def keypoints_batch(self, images):
         """Keypoints of a sequence of frames (all numpy / host, or all device tensors).
 
@@ -72,40 +114,8 @@ class BatchPlan(SiftPlan):
             return []
         with self._sem:
             L = _lib.lib()
-            key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
-            if key != self._par_key:
-                params = self._current_params()
-                _lib.check(L.siftmi_batch_set_params(self._handle, C.byref(params)))
-                self._params, self._par_key = params, key
-            ptrs = (C.c_void_p * n)()
-            keep = []
-            dev_flags = set()
-            code = None
-            for i, image in enumerate(images):
-                ptr, is_dev, dtype, shape, k = _pointer_of(image)
-                assert tuple(shape[:2]) == tuple(self.shape)
-                assert dtype in [self.dtype, numpy.float32]
-                if dtype == numpy.float32 and len(shape) == 2:
-                    c = _lib.DTYPE_CODES["float32"]
-                elif self.dtype == numpy.float64 and dtype == numpy.float64:
-                    k = k.float() if is_dev else k.astype(numpy.float32)
-                    ptr = k.data_ptr() if is_dev else k.ctypes.data
-                    c = _lib.DTYPE_CODES["float32"]
-                elif len(shape) == 3 and dtype == numpy.uint8 and self.RGB:
-                    c = _lib.DTYPE_CODES["rgb8"]
-                elif self.dtype in self.converter and len(shape) == 2:
-                    c = _lib.DTYPE_CODES[self.dtype.name]
-                else:
-                    raise RuntimeError("invalid input format error (%s)" % (str(self.dtype)))
-                if code is None:
-                    code = c
-                elif c != code:
-                    raise RuntimeError("all frames of a batch must have the same element type")
-                ptrs[i] = ptr
-                keep.append(k)
-                dev_flags.add(int(bool(is_dev)))
-            if len(dev_flags) != 1:
-                raise RuntimeError("the frames of a batch must be all host arrays or all device tensors")
+            self._sync_params(L)
+            ptrs, code, is_dev, keep = self._marshal(images)
             counts = (C.c_int64 * n)()
             offsets = (C.c_int64 * n)()
             parked = C.c_int64(0)
@@ -124,7 +134,7 @@ class BatchPlan(SiftPlan):
                     arrays[i] = numpy.empty(cap, dtype=self.dtype_kp)
                     outs[i] = arrays[i].ctypes.data
                     caps[i] = cap
-            _lib.check(L.siftmi_batch_keypoints_into(self._handle, ptrs, n, code, dev_flags.pop(), outs if direct else None,
+            _lib.check(L.siftmi_batch_keypoints_into(self._handle, ptrs, n, code, is_dev, outs if direct else None,
                                                      caps if direct else None, counts, offsets, C.byref(parked), C.byref(ovf)))
             self.overflow = bool(ovf.value)
             if self.overflow:
@@ -142,6 +152,41 @@ class BatchPlan(SiftPlan):
             self._records_per_frame = max(1.0, sum(counts) / float(n))
             del keep
         return result
+
+    def keypoints_batch_device(self, images):
+        """Same as ``keypoints_batch`` but the records stay in HBM: returns ``(counts, records)`` where `records` is a
+        torch uint8 tensor on this plan's device holding the 144-byte records of frame 0, frame 1, ... back to back
+        (``sum(counts) * 144`` bytes).  This is what the multi-GPU exchange (``gather_records_device``) consumes: no
+        host staging between the descriptor kernels and the RCCL all-gather."""
+        import torch
+        images = list(images)
+        n = len(images)
+        dev = torch.device("cuda", self.device)
+        if n == 0:
+            return [], torch.empty(0, dtype=torch.uint8, device=dev)
+        with self._sem:
+            L = _lib.lib()
+            self._sync_params(L)
+            ptrs, code, is_dev, keep = self._marshal(images)
+            counts = (C.c_int64 * n)()
+            offsets = (C.c_int64 * n)()
+            parked = C.c_int64(0)
+            ovf = C.c_int32(0)
+            _lib.check(L.siftmi_batch_keypoints_into(self._handle, ptrs, n, code, is_dev, None, None, counts, offsets,
+                                                     C.byref(parked), C.byref(ovf)))
+            self.overflow = bool(ovf.value)
+            out = torch.empty(max(1, parked.value) * RECORD_BYTES, dtype=torch.uint8, device=dev)
+            if parked.value:
+                _lib.check(L.siftmi_batch_fetch(self._handle, out.data_ptr(), 1, 0, parked.value))
+            # the arena holds the frames in retirement order; hand them back in input order
+            cnt = [int(c) for c in counts]
+            off = [int(o) for o in offsets]
+            if any(off[i] != sum(cnt[:i]) for i in range(n)):
+                parts = [out[off[i] * RECORD_BYTES:(off[i] + cnt[i]) * RECORD_BYTES] for i in range(n)]
+                out = torch.cat(parts) if parts else out
+            self._records_per_frame = max(1.0, sum(cnt) / float(n))
+            del keep
+        return cnt, out[:sum(cnt) * RECORD_BYTES]
 
     def keypoints(self, image):
         return self.keypoints_batch([image])[0]
@@ -204,12 +249,56 @@ def gather_records(local_records, n_items, rank, world_size, device=None, group=
     return out
 
 
+def gather_records_device(counts, records, n_items, rank, world_size, group=None):
+    """The exchange step on device tensors (backend "nccl" = RCCL over xGMI): all-gather of the per-image counts, then
+    of the record bytes padded to the largest per-rank total.  Nothing is staged through the host; the only host
+    read-back is the (world_size x per_rank) count table that sizes the payload.
+
+    :param counts: records per owned image, in the order of shard_indices(n_items, rank, world_size)
+    :param records: torch uint8 device tensor, the owned images' records back to back
+    :return: (all_counts, gathered): all_counts[r][j] = records of the j-th image of rank r (python ints); gathered =
+             device uint8 tensor (world_size, max_total * 144): row r holds rank r's records back to back
+    """
+    import torch
+    import torch.distributed as dist
+
+    dev = records.device
+    per_rank = (n_items + world_size - 1) // world_size
+    mine = torch.zeros(per_rank, dtype=torch.int64)
+    mine[:len(counts)] = torch.tensor([int(c) for c in counts], dtype=torch.int64) if counts else mine[:0]
+    mine = mine.to(dev)
+    table = torch.empty(world_size * per_rank, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(table, mine, group=group)
+    table = table.view(world_size, per_rank)
+    all_counts = table.cpu().tolist()                       # 8 bytes per image: sizes the payload
+    max_total = max(1, max(sum(row) for row in all_counts))
+    payload = torch.zeros(max_total * RECORD_BYTES, dtype=torch.uint8, device=dev)
+    payload[:records.numel()] = records
+    gathered = torch.empty(world_size * payload.numel(), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, payload, group=group)
+    return all_counts, gathered.view(world_size, -1)
+
+
+def split_gathered(all_counts, gathered, n_items, world_size):
+    """Per-image numpy recarrays from the result of gather_records_device (one device-to-host copy of everything)."""
+    host = gathered.cpu().numpy()
+    out = [None] * n_items
+    for r in range(world_size):
+        at = 0
+        for j, idx in enumerate(shard_indices(n_items, r, world_size)):
+            n = int(all_counts[r][j])
+            out[idx] = host[r, at:at + n * RECORD_BYTES].copy().view(SiftPlan.dtype_kp).view(numpy.recarray)
+            at += n * RECORD_BYTES
+    return out
+
+
 def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, device=None, **plan_kwargs):
     """Keypoints of a list of same-shape images, sharded over the ranks of the default process group.
 
     Each rank runs its share through a ``BatchPlan`` (pipelined, one result copy); without an initialised process
     group everything runs on one GPU.  Every rank must pass the same `images` list (only the owned ones are touched).
-    A ``SiftPlan`` passed as `plan` is used frame by frame.
+    A ``SiftPlan`` passed as `plan` is used frame by frame.  With the "nccl" backend (RCCL) the exchange runs on device
+    tensors end to end (``gather_records_device``); other backends (the gloo rehearsal on CPU) stage through the host.
     """
     import torch.distributed as dist
 
@@ -221,6 +310,12 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
     mine = shard_indices(len(images), rank, world_size)
     if plan is None and mine:
         plan = BatchPlan(template=images[mine[0]], **plan_kwargs)
+    on_device = (gather and world_size > 1 and isinstance(plan, BatchPlan) and dist.is_initialized()
+                 and dist.get_backend() == "nccl")
+    if on_device:
+        counts, records = plan.keypoints_batch_device([images[i] for i in mine])
+        all_counts, gathered = gather_records_device(counts, records, len(images), rank, world_size)
+        return split_gathered(all_counts, gathered, len(images), world_size)
     if isinstance(plan, BatchPlan):
         local = plan.keypoints_batch([images[i] for i in mine])
     else:

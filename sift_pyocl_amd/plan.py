@@ -51,8 +51,9 @@ class _DeviceRecords(object):
 
     def __init__(self, ptr, n, owner):
         self._owner = owner
+        self.count = int(n)
         self.shape = (n * 144,)
-        self.__cuda_array_interface__ = {"shape": (n * 144,), "typestr": "|u1", "data": (ptr, True), "version": 2, "strides": None}
+        self.__cuda_array_interface__ = {"shape": (n * 144,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
 
 
 class SiftPlan(object):

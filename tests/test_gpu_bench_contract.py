@@ -1,5 +1,7 @@
 """The driver's contract for bench.py and __graft_entry__ on a GPU box: one JSON line with the agreed keys, roofline and
-cpu_baseline objects; smoke() passes.  (The N > 1 branch is rehearsed with two gloo ranks sharing the GPU.)"""
+cpu_baseline objects; smoke() passes.  The N > 1 branch is rehearsed with two ranks sharing the GPU (RCCL refuses two
+ranks on one device, so their collectives run over gloo): once through bench.py's own launcher (`--gpus 2`, no
+torch.distributed.run), once under torch.distributed.run as the driver starts it, and once for the C4 workload."""
 import json
 import os
 import subprocess
@@ -19,12 +21,12 @@ def run(cmd, timeout=600):
     return json.loads(lines[0])
 
 
-def check_common(d, n_gpus, steps, warmup):
+def check_common(d, n_gpus, steps, warmup, scaling="weak"):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
-    assert d["unit"] == "Mpix/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "Mpix/s" and d["higher_is_better"] is True and d["scaling"] == scaling and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1000 and d["ms_per_step"] > 0
     r = d["roofline"]
@@ -43,6 +45,10 @@ def test_bench_single_gpu_line():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     # value is throughput of K steps of one 4096 x 4096 image: consistent with ms_per_step
     assert abs(d["value"] - 4096 * 4096 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    assert "blur_team_kernel" in d["roofline"]["kernel"] and "cpu" in c
+    for key in ("pipelined", "host_to_host", "match_100k"):
+        assert key in d and "error" not in d[key], (key, d.get(key))
+    assert d["match_100k"]["pairs"] == d["match_100k"]["expected_pairs"]
 
 
 def test_bench_two_ranks_rehearsal():
@@ -51,6 +57,24 @@ def test_bench_two_ranks_rehearsal():
     check_common(d, 2, 3, 1)
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
     assert abs(d["value"] - 2 * 4096 * 4096 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` starts the two ranks itself (no torch.distributed.run) and reports the world size the
+    process group observed."""
+    d = run([sys.executable, "bench.py", "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1"])
+    check_common(d, 2, 2, 1)
+    assert d["config"]["world_size_observed"] == 2 and d["config"]["backend"] == "gloo" and "all_gather" in d["config"]["exchange"]
+
+
+def test_bench_c4_sharded_batch():
+    """BASELINE.json configs[3]: 64 x 2048^2 frames sharded over the ranks + all-gather of every frame's records."""
+    d = run([sys.executable, "bench.py", "--config", "c4", "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "1"], timeout=900)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["name"] == "c4" and d["config"]["images_per_step"] == 64
+    assert 1500 < d["config"]["keypoints_per_image"] < 4000          # ~2.7 k per 2048^2 white-noise frame
+    assert abs(d["value"] - 64 * 2048 * 2048 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    one = run([sys.executable, "bench.py", "--config", "c4", "--steps", "1", "--warmup", "1"], timeout=900)
+    assert one["n_gpus"] == 1 and abs(one["config"]["keypoints_per_image"] - d["config"]["keypoints_per_image"]) < 1e-6
 
 
 def test_graft_entry_smoke():

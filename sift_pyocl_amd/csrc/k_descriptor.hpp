@@ -39,7 +39,8 @@ namespace siftk {
 #endif
 
 struct alignas(16) DescRowLds {
-    float pool[1024];                          // [0, 896): <= 512 values, every bin's segment padded to a multiple of 4; [960 + lane]: dump slots
+    float pool[1024];                          // [0, 896): <= 512 values, every bin's segment zero-padded to a multiple of 4;
+                                               // [896, 900): zeros, read by an owner past the end of its segment; [960 + lane]: dump slots
     float V[128];
     uint2 mask[128];                           // per bin: 64-bit mask of contributing lanes (x: lanes 0-31, y: lanes 32-63)
     unsigned mbase[128];                       // per bin: pool position of the first contributor
@@ -120,6 +121,7 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
     if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
     siftmath::load_atan_fold(fold);
     L.mask[lane] = make_uint2(0u, 0u); L.mask[lane + 64] = make_uint2(0u, 0u);
+    if (lane < 4) L.pool[896 + lane] = 0.0f;
     __syncthreads();                     // the only workgroup barrier: the fold table
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const unsigned lo_mask = (lane < 32) ? ((1u << lane) - 1u) : 0xffffffffu;
@@ -248,6 +250,10 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
             const int base_b = base_a + pa;
             L.mbase[lane] = (unsigned)base_a;
             L.mbase[lane + 64] = (unsigned)base_b;
+            // the last group of four of every segment starts as +0: its padding then adds +0 (an exact no-op on these
+            // non-negative sums), so the owners' loop needs no per-element masks
+            if (cnta) pool4[(base_a + pa - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cntb) pool4[(base_b + pb - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
             __builtin_amdgcn_wave_barrier();
             // ---- 3c. every value to segment base + rank among the contributors of its bin.  Branch free, so that the 16
             //          LDS reads are in flight together (exec-masked blocks would serialise them); a lane without a
@@ -269,18 +275,19 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- 3d. ordered sums, four values per read (the padding of a segment holds stale values: masked), the next
-            //          read in flight while the current four are added
-            const float4 *pa4 = pool4 + (base_a >> 2), *pb4 = pool4 + (base_b >> 2);
+            // ---- 3d. ordered sums, four values per read, the next read in flight while the current four are added; past
+            //          the end of its own segment a lane reads the four zeros at [896]
             const int nmax = ABL(14) ? 0 : max(pa, pb);
-            float4 va = pa4[0], vb = pb4[0];
-            for (int k0 = 0; k0 < nmax; k0 += 4) {
+            const int qa = base_a >> 2, qb = base_b >> 2, ea = pa >> 2, eb = pb >> 2;
+            float4 va = pool4[ea ? qa : 224], vb = pool4[eb ? qb : 224];
+            for (int g4 = 0; g4 < (nmax >> 2); g4++) {
                 const float4 ca = va, cb = vb;
-                va = pa4[((k0 >> 2) + 1) & 63]; vb = pb4[((k0 >> 2) + 1) & 63];
-                acc0 = acc0 + ((k0 < cnta) ? ca.x : 0.0f); acc1 = acc1 + ((k0 < cntb) ? cb.x : 0.0f);
-                acc0 = acc0 + ((k0 + 1 < cnta) ? ca.y : 0.0f); acc1 = acc1 + ((k0 + 1 < cntb) ? cb.y : 0.0f);
-                acc0 = acc0 + ((k0 + 2 < cnta) ? ca.z : 0.0f); acc1 = acc1 + ((k0 + 2 < cntb) ? cb.z : 0.0f);
-                acc0 = acc0 + ((k0 + 3 < cnta) ? ca.w : 0.0f); acc1 = acc1 + ((k0 + 3 < cntb) ? cb.w : 0.0f);
+                va = pool4[(g4 + 1 < ea) ? qa + g4 + 1 : 224];
+                vb = pool4[(g4 + 1 < eb) ? qb + g4 + 1 : 224];
+                acc0 = acc0 + ca.x; acc1 = acc1 + cb.x;
+                acc0 = acc0 + ca.y; acc1 = acc1 + cb.y;
+                acc0 = acc0 + ca.z; acc1 = acc1 + cb.z;
+                acc0 = acc0 + ca.w; acc1 = acc1 + cb.w;
             }
             __builtin_amdgcn_wave_barrier();
             if (cnta) L.mask[lane] = make_uint2(0u, 0u);

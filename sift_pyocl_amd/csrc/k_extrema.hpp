@@ -23,21 +23,43 @@ struct BlurPlanes { const float *p[6]; };
 __device__ __forceinline__ float dog_at(const BlurPlanes &b, int s, size_t pos) { return b.p[s][pos] - b.p[s + 1][pos]; }
 
 // 80 VGPRs (12 B of scratch) = 6 waves per SIMD instead of the natural 81 = 5: the kernel is latency bound (PMC: 70 % of
-// the wave time in s_waitcnt), 8 waves (64 VGPRs, 64 B of scratch) is twice as slow
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, double contrast,
+// the wave time in s_waitcnt), 8 waves (64 VGPRs, 64 B of scratch) is twice as slow.
+//
+// Candidates are appended to ONE list through one device-scope counter.  Same-address atomics are served one at a time by
+// the L2 (measured 5.2 ns each: 20 k candidates = 104 us of a 118 us kernel, 200 k = 1 ms), so a lane never touches the
+// counter itself: a wave parks its candidates in LDS (order-preserving ballot compaction), reserves slots for a whole
+// buffer at once, and the four waves of a workgroup share a single atomicAdd for what is left at the end of their strips.
+#ifndef SIFT_EXT_WAVES
+#define SIFT_EXT_WAVES 5      // 92 VGPRs without scratch; forcing 6 waves (80 VGPRs) now spills 11 registers in the row loop: 0.18 ms instead of 0.10
+#endif
+#define SIFT_EXT_BUF 128          // candidates a wave parks before reserving slots (a row adds at most 3 x 62)
+struct ExtWaveLds { float4 buf[SIFT_EXT_BUF + 192]; };
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, double contrast,
                                                       float edth, float4 *__restrict__ cand,
                                                       int *__restrict__ counter, int capacity) {
+    __shared__ ExtWaveLds lds_all[4];
+    __shared__ int s_pending[4], s_base;
     const int lane = threadIdx.x & 63;
+    ExtWaveLds &L = lds_all[threadIdx.x >> 6];
     const int nx = (W - 2 * border + 61) / 62;
     const int ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= nx * ny) return;
-    const int sx = wid % nx, sy = wid / nx;
+    const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
+    const int sx = active ? wid % nx : 0, sy = active ? wid / nx : 0;
     const int x = border + sx * 62 + lane - 1;
     const int xc = min(max(x, 0), W - 1);
     const bool col_ok = (lane >= 1) && (lane <= 62) && (x < W - border);
     const int ya = border + sy * SIFT_EXT_ROWS;
-    const int yb = min(ya + SIFT_EXT_ROWS, H - border);
+    const int yb = active ? min(ya + SIFT_EXT_ROWS, H - border) : ya - 2;
+
+    int pending = 0;                                     // candidates parked in L.buf (wave uniform)
+    auto store_pending = [&](int slot, int count) {
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < count; e += 64)
+            if (slot + e < capacity) cand[slot + e] = L.buf[e];
+        __builtin_amdgcn_wave_barrier();
+    };
 
     float hM[3][3], hm[3][3];   // [row slot][scale]: horizontal+scale max / min for rows y-2, y-1, y
     float ctr[3] = {0.f, 0.f, 0.f}, ctr_next[3];
@@ -47,10 +69,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         for (int k = 0; k < 3; k++) { hM[r][k] = 0.f; hm[r][k] = 0.f; }
 
     float vn[6];                                     // next row's samples, loaded one iteration ahead
-    {
+    if (active) {
         const size_t pos0 = (size_t)(ya - 1) * W + xc;
 #pragma unroll
         for (int k = 0; k < 6; k++) vn[k] = b.p[k][pos0];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) vn[k] = 0.f;
     }
     for (int y = ya - 1; y <= yb; y++) {
         float v[6];
@@ -78,8 +103,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             ctr_next[k] = d[k + 1];
         }
         // centre row is y-1; it is complete once rows y-2, y-1, y have been seen
+        bool found[3] = {false, false, false};
+        const int yc = y - 1;
         if (y >= ya + 1 && col_ok) {
-            const int yc = y - 1;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float val = ctr[k];
@@ -100,16 +126,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                         const float H01 = (float)((double)dd / 4.0);
                         const float det = H00 * H11 - H01 * H01;
                         const float tr = H00 + H11;
-                        if (!(det < edth * tr * tr) && val != 0.0f) {
-                            const int old = atomicAdd(counter, 1);
-                            if (old < capacity) cand[old] = make_float4(val, (float)yc, (float)x, (float)s);
-                        }
+                        found[k] = !(det < edth * tr * tr) && val != 0.0f;
                     }
                 }
             }
         }
+        // park this row's candidates (ballot compaction: no atomics)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const unsigned long long m = __ballot(found[k]);
+            if (m) {                                                  // wave uniform
+                if (found[k]) L.buf[pending + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(ctr[k], (float)yc, (float)x, (float)(k + 1));
+                pending += __popcll(m);
+            }
+        }
+        if (pending > SIFT_EXT_BUF) {                                 // wave uniform: reserve slots for the whole buffer
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(counter, pending);
+            store_pending(__shfl(slot, 0), pending);
+            pending = 0;
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) ctr[k] = ctr_next[k];
+    }
+    // ---- what is left leaves with one atomicAdd per workgroup
+    if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_pending[0] + s_pending[1] + s_pending[2] + s_pending[3];
+        s_base = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    {
+        const int w = threadIdx.x >> 6;
+        int slot = s_base;
+        for (int q = 0; q < w; q++) slot += s_pending[q];
+        store_pending(slot, pending);
     }
 }
 

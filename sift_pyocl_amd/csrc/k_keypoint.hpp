@@ -134,10 +134,13 @@ __device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/
 // and gets a 16-byte aligned segment of a small value pool from a wave prefix sum of the vote counts; every voter stores
 // its value at segment base + (number of lower lanes voting for the same bin); the owner adds its segment front to back
 // (ascending lane == raster order), four values per LDS read.  atan2 / exp: Ziv fast paths of siftmath.hpp.
+#define SIFT_ORI_OBUF 96          // a keypoint yields at most 36 entries (1 + 35 further peaks)
 struct alignas(16) OriWaveLds {
     float pool[64 + 36 * 3 + 4];   // 64 values, every bin's segment padded to a multiple of 4
     uint2 mask[36];
     unsigned mbase[36];
+    float4 obuf[SIFT_ORI_OBUF];    // oriented keypoints waiting for their slots in the global list
+    int oaux[SIFT_ORI_OBUF];
 };
 
 __device__ __forceinline__ int wave_prefix_incl(int x) {      // inclusive prefix sum over the 64 lanes (DPP, no LDS)
@@ -151,6 +154,10 @@ __device__ __forceinline__ int wave_prefix_incl(int x) {      // inclusive prefi
     return t;
 }
 
+// Slots in the global oriented list come from ONE device-scope counter.  Same-address atomics are served one at a time
+// by the L2 (measured: 5.2 ns each), so an atomicAdd per keypoint made the counter the bottleneck of the kernel (half of
+// its time at 120 k keypoints).  A wave therefore parks its results in LDS and reserves slots for many keypoints at once;
+// at the end the four waves of a workgroup share a single atomicAdd.
 __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float ori_sigma,
                                                           const float4 *__restrict__ kp,
                                                           const int *__restrict__ kp_aux, Counters *cnt, int group,
@@ -169,6 +176,21 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
     const int first = cnt->grp_kp_start[group];
     if (threadIdx.x == 0 && blockIdx.x == 0 && cnt->n_kp > kp_capacity) cnt->overflow = 1;
     const float4 *pool4 = reinterpret_cast<const float4 *>(L.pool);
+    __shared__ int s_pending[4], s_base;
+    int pending = 0;                     // entries parked in L.obuf (wave uniform)
+    auto store_pending = [&](int slot, int count) {
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < count; e += 64) {
+            if (slot + e < out_capacity) { okp[slot + e] = L.obuf[e]; oaux[slot + e] = L.oaux[e]; }
+            else cnt->overflow = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto flush_wave = [&](int count) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&cnt->n_out, count);
+        store_pending(__shfl(slot, 0), count);
+    };
     for (int i = first + wave; i < n; i += nwaves) {
         const float4 k = kp[i];          // (peak, row, col, sigma)
         const int aux = kp_aux[i];       // detection scale | octave << 8
@@ -183,12 +205,14 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         const int rmax = min(row + radius, H - 2), cmax = min(col + radius, W - 2);
         const float lim = (float)(radius * radius) + 0.5f;
         const float two_s2 = 2.0f * sigma * sigma;
+        // the two divisions per sample (orientation_cpu.cl:88-90) go through siftmath::div_by_reciprocal (same quotient)
+        const float r_two_s2 = 1.0f / two_s2;
+        const bool fast_div = two_s2 >= 1e-3f && two_s2 <= 1e6f;
         const int wc = cmax - cmin + 1, hr = rmax - rmin + 1;
         const int total = (wc > 0 && hr > 0) ? wc * hr : 0;
         const float inv_wc = 1.0f / (float)max(wc, 1);
         float h = 0.0f;                  // lane b < 36 owns hist[b]
-        // sample position of this lane in the batch starting at `base`; the loads of batch b+1 are issued before
-        // batch b is evaluated
+        // sample position of this lane in the batch starting at `base`
         auto locate = [&](int base, int &r, int &c) {
             const int idx = base + lane;
             if (idx >= total) return false;
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         int nr = 0, nc = 0;
         bool nvalid = locate(0, nr, nc);
         GradTaps ntaps = {};
-        if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);
+        if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);   // the loads of batch b+1 are issued before batch b is evaluated
         for (int base = 0; base < total; base += 64) {
             bool valid = nvalid;
             const int r = nr, c = nc;
@@ -221,10 +245,10 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 valid = (gval > 0.0f) && (distsq < lim);
                 if (valid) {
                     const float a = siftmath::atan2f_fast(-gy, gx, fold);
-                    bin = (int)(36.0f * (a + SM_PI_F + 0.001f) / (2.0f * SM_PI_F));
+                    bin = (int)siftmath::div_by_reciprocal(36.0f * (a + SM_PI_F + 0.001f), 2.0f * SM_PI_F, 1.0f / (2.0f * SM_PI_F));
                     valid = (bin >= 0) && (bin <= 36);
                     bin = min(max(bin, 0), 35);
-                    val = siftmath::expf_fast(-distsq / two_s2) * gval;
+                    val = siftmath::expf_fast(fast_div ? siftmath::div_by_reciprocal(-distsq, two_s2, r_two_s2) : -distsq / two_s2) * gval;
                 }
                 if (valid) atomicOr(reinterpret_cast<unsigned *>(L.mask) + 2 * bin + (lane >> 5), 1u << (lane & 31));
             }
@@ -255,15 +279,22 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             if (votes) L.mask[lane] = make_uint2(0u, 0u);
             __builtin_amdgcn_wave_barrier();
         }
-        // six passes of circular [1 1 1]/3 smoothing; hist[35] sees the already updated hist[0];
-        // the division is by the double literal 3.0 (orientation_cpu.cl:101-109)
+        // six passes of circular [1 1 1]/3 smoothing; hist[35] sees the already updated hist[0].  The reference divides
+        // in double, (float)((double)s / 3.0) (orientation_cpu.cl:101-109): for a float s the double quotient lies at
+        // least |s| / (24 ulp) away from every float rounding boundary (3 x midpoint is never a float), so the double
+        // rounding is harmless and the value is the correctly rounded float quotient s / 3.0f -- computed here by
+        // siftmath::div_by_reciprocal (tiny sums, where its residuals could underflow, take the double division).
         const int lp = (lane == 0) ? 35 : lane - 1, ln = (lane >= 35) ? 0 : lane + 1;
+        auto third = [&](float s) {
+            return (__builtin_fabsf(s) >= 1e-25f && __builtin_fabsf(s) <= 1e30f) ? siftmath::div_by_reciprocal(s, 3.0f, 1.0f / 3.0f)
+                                                                            : (float)((double)s / 3.0);
+        };
 #pragma unroll 1
         for (int pass = 0; pass < 6; pass++) {
             const float prev = __shfl(h, lp), nxt = __shfl(h, ln);
-            float nh = (float)((double)((prev + h) + nxt) / 3.0);
+            float nh = third((prev + h) + nxt);
             const float nh0 = __shfl(nh, 0);
-            if (lane == 35) nh = (float)((double)((prev + h) + nh0) / 3.0);
+            if (lane == 35) nh = third((prev + h) + nh0);
             h = (lane < 36) ? nh : 0.0f;
         }
         float mx = (lane < 36) ? h : 0.0f;
@@ -290,22 +321,29 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         const float sum4 = ((ox + oy) + os) + angle;
         const int nmain = (sum4 == sum4) ? 1 : 0;     // host NaN sieve of plan.py:545-550, done here
         const int nextra = __popcll((unsigned long long)emask);
-        int slot0 = 0;
-        if (lane == 0 && nmain + nextra > 0) slot0 = ABL(4) ? (i * 4) : atomicAdd(&cnt->n_out, nmain + nextra);
-        slot0 = __shfl(slot0, 0);
-        if (lane == 0 && nmain) {
-            if (slot0 < out_capacity) {
-                okp[slot0] = make_float4(ox, oy, os, angle);
-                oaux[slot0] = aux;
-            } else cnt->overflow = 1;
-        }
+        // park the results of this keypoint in the wave's LDS buffer (flushed when the next keypoint might not fit)
+        if (pending + nmain + nextra > SIFT_ORI_OBUF) { flush_wave(pending); pending = 0; }
+        if (lane == 0 && nmain) { L.obuf[pending] = make_float4(ox, oy, os, angle); L.oaux[pending] = aux; }
         if (extra) {
-            const int slot = slot0 + nmain + __popcll((unsigned long long)(emask & ((1ull << lane) - 1ull)));
-            if (slot < out_capacity) {
-                okp[slot] = make_float4(ox, oy, os, a2);
-                oaux[slot] = aux;
-            } else cnt->overflow = 1;
+            const int at = pending + nmain + __popcll((unsigned long long)(emask & ((1ull << lane) - 1ull)));
+            L.obuf[at] = make_float4(ox, oy, os, a2);
+            L.oaux[at] = aux;
         }
+        pending += nmain + nextra;
+    }
+    // ---- the workgroup's remaining entries leave with a single atomicAdd
+    if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = s_pending[0] + s_pending[1] + s_pending[2] + s_pending[3];
+        s_base = tot ? atomicAdd(&cnt->n_out, tot) : 0;
+    }
+    __syncthreads();
+    {
+        const int w = threadIdx.x >> 6;
+        int slot = s_base;
+        for (int q = 0; q < w; q++) slot += s_pending[q];
+        store_pending(slot, pending);
     }
 }
 

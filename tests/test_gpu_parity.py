@@ -106,7 +106,8 @@ def test_division_by_reciprocal_is_the_ieee_quotient(siftlib):
     """siftmath::div_by_reciprocal (Markstein's two residual steps on a correctly rounded reciprocal) replaces the
     two divisions per descriptor sample (keypoints_cpu.cl:64-65): it must return the correctly rounded quotient for the
     operands that occur there -- |a| < 2^8 (window coordinates, incl. exact zeros and values that cancel to a few ulp),
-    b = spacing in [0.1, 128].  numpy's float32 division is the IEEE quotient."""
+    b = spacing in [0.1, 128] -- and for the two divisions per orientation sample (orientation_cpu.cl:88-90:
+    x / (2 pi_f), -d2 / (2 sigma^2) with |a| up to 10^4, b in [1e-3, 1e6]).  numpy's float32 division is the IEEE quotient."""
     rng = np.random.default_rng(77)
     n = 1 << 22
     for rnd in range(24):
@@ -118,6 +119,9 @@ def test_division_by_reciprocal_is_the_ieee_quotient(siftlib):
         else: a = (rng.standard_normal(n) * 10.0 ** rng.integers(-7, 2, n)).astype(np.float32)
         a[:3] = [0.0, -0.0, 1.0]
         if rnd == 5: b = rng.integers(0x3dcccccd, 0x43000000, n).astype(np.uint32).view(np.float32)       # every spacing pattern class
+        if rnd >= 12:                                                                                      # the orientation kernel's operands
+            b = np.exp(rng.uniform(np.log(1e-3), np.log(1e6), n)).astype(np.float32) if rnd % 2 else np.full(n, 2.0 * np.float32(3.14159274101257), np.float32)
+            a = (a * np.float32(40.0)).astype(np.float32)
         out = np.empty(n, np.float32)
         assert siftlib.siftmi_stage_math(0, 7, _p(a), _p(b), _p(out), n) == 0
         want = a / b

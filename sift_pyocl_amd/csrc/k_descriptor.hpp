@@ -124,8 +124,6 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
     if (lane < 4) L.pool[896 + lane] = 0.0f;
     __syncthreads();                     // the only workgroup barrier: the fold table
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-    const unsigned lo_mask = (lane < 32) ? ((1u << lane) - 1u) : 0xffffffffu;
-    const unsigned hi_mask = (lane < 32) ? 0u : ((1u << (lane - 32)) - 1u);
 
     for (int i = start + gwave; i < end; i += nwaves) {
         const float4 kq = okp[i];        // (x, y, sigma*oct, angle)

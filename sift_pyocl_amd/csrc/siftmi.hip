@@ -96,9 +96,10 @@ struct Options {
     int march_wgs = 0;       // workgroups wanted by the one-block form (0: default)
     int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
     int ori_blocks = 1024, ori_pad = 0;
-    int desc_blocks = 2048, desc_pad = -1;   // wave form of the descriptor kernel; -1: residency heuristic
+    int desc_blocks = 2048, desc_pad = 0;    // descriptor launch: workgroups, bytes of dynamic LDS (residency throttle)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
+    int chain0 = 1;          // octave 0 end to end on the pyramid stream, later octaves' pyramids on the second chain
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
 };
@@ -303,10 +304,11 @@ void launch_blur_generic(hipStream_t st, const float *in, float *out, float *tmp
     hipLaunchKernelGGL(blur_generic_pass, grid, dim3(256), 0, st, (const float *)tmp, out, W, H, t.dev, t.n, 1, mm, 0);
 }
 
-void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm) {
-    bool ok = norm ? launch_blur_tiled<true>(p->opt, p->stream, in, out, W, H, t, p->mm)
-                   : launch_blur_tiled<false>(p->opt, p->stream, in, out, W, H, t, p->mm);
-    if (!ok) launch_blur_generic(p->stream, in, out, p->tmp, W, H, t, p->mm, norm);
+void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm, hipStream_t st = nullptr) {
+    if (!st) st = p->stream;
+    bool ok = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm)
+                   : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm);
+    if (!ok) launch_blur_generic(st, in, out, p->tmp, W, H, t, p->mm, norm);
 }
 
 bool taps_symmetric(const Taps &t) {
@@ -425,14 +427,11 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         snprintf(lab, sizeof lab, "descriptors group %d", group);
         Scope sc(p, lab, false, 0, st);
         const int desc_blocks = p->opt.desc_blocks;
-        // Residency throttle.  With few keypoints (a white-noise 4096^2 frame has ~8 k in octave 0) the descriptor kernel is
-        // not the bottleneck, but at full occupancy (5 waves per SIMD x 96 VGPRs) it leaves no registers for the
-        // later octaves' blur / detection kernels, whose chain then trails it by > 100 us.  20 KB of unused dynamic LDS
-        // cap it at 3 blocks per CU; the later-octave kernels slip in (-4 % per image).  Keypoint-dense frames
-        // (> 20 k in octave 0, judged by the previous frame of this plan) are descriptor-bound and run unthrottled (+12 %).
-        const int desc_pad_env = p->opt.desc_pad;
-        int desc_pad = (group == 0 && p->overlap && p->n_oct > 1 && p->last_group0 <= 20000) ? 20000 : 0;
-        if (desc_pad_env >= 0) desc_pad = desc_pad_env;
+        // Optional residency throttle (option "desc_pad": bytes of unused dynamic LDS per workgroup).  Round 1 capped the
+        // octave-0 launch at 3 workgroups per CU so that the later octaves' kernels found registers; with the round-2
+        // kernels (shorter detection chain, 4 workgroups per CU by registers) the unthrottled launch is faster
+        // (0.96 against 1.01 ms per 4096^2 frame), so the default is 0.
+        const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
         if (p->desc_rows && !p->opt.desc_stream)
             hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                                (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
@@ -507,7 +506,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     // Stream priorities (pyramid and later-octave streams above the octave-0 detection stream, whose long orientation /
     // descriptor kernels would otherwise win every dispatch slot) pay off where two multi-stream plans share the GPU
     // (BatchPlan with 2 lanes of large frames: 1.13 instead of 1.33 ms per 4096^2 frame); for a single plan they are
-    // within noise, and once a process has created prioritised streams its normal-priority streams get fewer hardware
+    // within noise (round 2, later-octave chain above the octave-0 chain: 0.962 against 0.972 ms), and once a process has created prioritised streams its normal-priority streams get fewer hardware
     // queues (8 single-stream lanes of 512^2 frames: 0.72 instead of 0.41 ms per frame).  Hence: only for the
     // multi-stream lanes of a batch.
     const bool prio = g_lane_mode == 2;
@@ -618,6 +617,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_pad") o.desc_pad = v;
     else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
+    else if (n == "chain0") o.chain0 = v != 0;
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
@@ -726,62 +726,65 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
 // work that touches plan-owned buffers only (so it can be captured once and replayed).  Sets p->fin.
 int enqueue_body(siftmi_plan *p) {
     char lab[96];
-    // Stream `stream` builds the pyramid of every octave back to back; `stream2` runs detection /
-    // description of octave o as soon as its six planes exist, overlapping the (small, latency-bound)
-    // pyramids of the following octaves.  Octave planes are never rewritten, so the only ordering needed is
-    // one event per octave.
+    // Two chains (option "overlap"): stream `stream` carries octave 0 end to end -- pyramid, detection, orientation,
+    // descriptors, read-back of the counters: the critical path of an image, without a cross-stream hop (~12 us each) on
+    // it; `stream3` builds the pyramids of the later octaves once octave 0's exists, detects and describes them (group 1:
+    // its detection waits until group 0's orientation pass has frozen its list ranges) and ends with its own read-back.
+    // Octave planes are never rewritten, so the only ordering needed is those two events.  (Option "chain0" = 0 restores
+    // the round-1 layout: every pyramid on `stream`, octave 0's detection on `stream2`.)
+    const bool two = p->overlap && p->n_oct > 0;
+    const bool chain0 = two && p->opt.chain0;
     for (int oct = 0; oct < p->n_oct; oct++) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
+        hipStream_t pyr = (chain0 && oct > 0) ? p->stream3 : p->stream;                     // builds this octave's planes
+        hipStream_t dst = !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : p->stream3);   // consumes them
+        if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
+        if (oct > 0) {
+            const int LW = p->ow[(size_t)oct - 1];
+            snprintf(lab, sizeof lab, "shrink %d", oct - 1);
+            Scope sc(p, lab, false, 0, pyr);
+            hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, pyr,
+                               (const float *)p->plane(oct - 1, 3), p->plane(oct, 0), LW, W, H);
+        }
         if (p->profile == 1) {
             if (oct == 0 && !p->chain) {          // no initial blur: the bracket opens here, five launches
                 Scope *ch = new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0);
                 if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
                 p->chain = ch;
             }
-            for (int s = 0; s < 5; s++) launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
+            for (int s = 0; s < 5; s++) launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr);
             if (oct == 0) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }
         } else {
             for (int s = 0; s < 5; s++) {
                 snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
-                Scope sc(p, lab, true, (double)W * H, nullptr, oct);
-                launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false);
+                Scope sc(p, lab, true, (double)W * H, pyr, oct);
+                launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr);
             }
         }
-        // group 0 = octave 0 on stream2, described right away; group 1 = every later octave on stream3: it
-        // starts once group 0's orientation pass has frozen its ranges and overlaps group 0's descriptors
-        hipStream_t dst = !p->overlap ? p->stream : (oct == 0 ? p->stream2 : p->stream3);
-        if (p->overlap) {
-            HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], p->stream));     // before the shrink: detection need not wait for it
+        if (two) {
+            if (oct == 0 || pyr != dst) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
-            HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
-        }
-        if (oct < p->n_oct - 1) {
-            const int SW = p->ow[(size_t)oct + 1], SH = p->oh[(size_t)oct + 1];
-            snprintf(lab, sizeof lab, "shrink %d", oct);
-            Scope sc(p, lab);
-            hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, p->stream,
-                               (const float *)p->plane(oct, 3), p->plane(oct + 1, 0), W, SW, SH);
+            if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
         }
         launch_detect_octave(p, oct, dst);
         if (oct == 0) launch_describe_group(p, 0, dst);
         else if (oct == p->n_oct - 1) {
             launch_describe_group(p, 1, dst);
-            if (p->overlap) HIPCHK(hipEventRecord(p->ev_grp1, dst));
+            if (two) HIPCHK(hipEventRecord(p->ev_grp1, dst));
         }
     }
     if (p->chain) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }   // no octave closed the light-profile bracket (n_oct == 0)
-    // Both detection streams rejoin the pyramid stream, which ends the image with the read-back of the counters.
+    // The image ends on the two chains.  Each reads the counter block back into its own pinned copy right after its
+    // descriptor kernel (the host takes the copy with the larger record count: n_out only grows) -- no rejoin hop.
     // (Capturing this fork / join into a hipGraph was tried: it replays correctly -- as long as stream3 does not rejoin
-    // through stream2, which crashes hipStreamEndCapture on ROCm 7.2 -- but a graph launch is no faster than the ~35 plain
+    // through stream2, which crashes hipStreamEndCapture on ROCm 7.2 -- but a graph launch is no faster than the plain
     // launches: small images are bound by the GPU-side latency of dependent kernels, not by host launch cost.)
-    // The image ends on the two detection streams.  Each reads the counter block back into its own pinned copy right
-    // after its descriptor kernel (the host takes the copy with the larger record count: n_out only grows), instead of
-    // both rejoining the pyramid stream first: two cross-stream hops (~20 us) less on the critical path.
     p->wait_a = p->stream; p->wait_b = nullptr;
-    if (p->overlap && p->n_oct > 0) {
-        if (p->profile) hipEventRecord(p->ev_last, p->stream2);
-        HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream2));
-        p->wait_a = p->stream2;
+    if (two) {
+        hipStream_t end0 = chain0 ? p->stream : p->stream2;
+        if (p->profile) hipEventRecord(p->ev_last, end0);
+        HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, end0));
+        p->wait_a = end0;
         if (p->n_oct > 1) {
             if (p->profile) hipEventRecord(p->ev_last_b, p->stream3);
             HIPCHK(hipMemcpyAsync(&p->hb->c2, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream3));

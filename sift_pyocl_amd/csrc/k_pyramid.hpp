@@ -559,8 +559,8 @@ template <int N, int NT, int S> struct March2Geom {
 // g+1 (prefetched registers -> buffer (g+1) % 3) and issues the loads of g+2.  One barrier per step.
 template <int N, bool NORM, int S, int DT = 0, int HW = 2>
 __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__restrict__ in, float *__restrict__ out,
-                                                          int W, int H, int nblocks, TapsArg<N> taps,
-                                                          const uint32_t *__restrict__ mm) {
+                                                          int W, int H, int nblocks, int last_subs, int rows_out,
+                                                          TapsArg<N> taps, const uint32_t *__restrict__ mm) {
     constexpr int NT = 128;                       // threads per team
     using G = March2Geom<N, NT, S>;
     using SS = SubSplit<N, S>;
@@ -572,7 +572,9 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
     const int role = threadIdx.x >= 64 * HW ? 1 : 0;            // wave-uniform
     const int tid = role ? (int)threadIdx.x - 64 * HW : (int)threadIdx.x;
     const int x0 = blockIdx.x * G::TX;
-    const int rows_out = nblocks * N - (N - 1);
+    // A segment outputs `rows_out` rows; it marches nblocks - 1 full accumulator periods of N rows and `last_subs` (1..S)
+    // sub-blocks of the last one: just enough rows to complete its outputs, so that the host can pick the segment height
+    // that balances the workgroups over the CUs instead of one quantised to multiples of N rows.
     const int ys = blockIdx.y * rows_out;
     const int yend = min(ys + rows_out, H);
     float mn = 0.f, range = 1.f;
@@ -720,18 +722,21 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
         }                                                                                                    \
     }
 
+    // step (blk, sub) exists?  (only the last period is partial)
+    auto exists = [&](int blk, int sub) { return blk < nblocks - 1 || (blk == nblocks - 1 && sub < last_subs); };
     // ---- prologue: the V team stages step 0 and looks ahead to step 1
     if (role == 1) {
         prefetch(0, 0, SS::pairs(0));
         stage(sbase, SS::pairs(0));
-        if (S > 1) prefetch(0, 1 % S, SS::pairs(1 % S));
-        else if (nblocks > 1) prefetch(1, 0, SS::pairs(0));
+        if (S > 1) { if (exists(0, 1 % S)) prefetch(0, 1 % S, SS::pairs(1 % S)); }
+        else if (exists(1, 0)) prefetch(1, 0, SS::pairs(0));
     }
     __syncthreads();
     int g = 0;                                     // step counter: buffer of step g is g % 3
     for (int blk = 0; blk < nblocks; blk++) {
 #pragma unroll
-        for (int sub = 0; sub < S; sub++, g++) {
+        for (int sub = 0; sub < S; sub++) {
+            if (blk == nblocks - 1 && sub >= last_subs) break;      // workgroup uniform
             float *cur = sbase + (g % 3) * BUF;
             if (role == 0) {
                 hpass(cur, SS::pairs(sub));
@@ -742,22 +747,26 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
                     if (sub == 0) { VPASS(prev, blk - 1, S - 1) } else { VPASS(prev, blk, (sub + S - 1) % S) }
                 }
                 // (2) stage step g+1 (already in registers) and look ahead to g+2
-                const bool has1 = (sub + 1 < S) || (blk + 1 < nblocks);
-                if (has1) {
+                const int sub1 = (sub + 1) % S, blk1 = blk + (sub + 1) / S;
+                if (exists(blk1, sub1)) {
                     float *nxt = sbase + ((g + 1) % 3) * BUF;
-                    stage(nxt, SS::pairs((sub + 1) % S));
+                    stage(nxt, SS::pairs(sub1));
                     const int sub2 = (sub + 2) % S;
                     const int blk2 = blk + (sub + 2) / S;
-                    if (blk2 < nblocks) prefetch(blk2, sub2, SS::pairs(sub2));
+                    if (exists(blk2, sub2)) prefetch(blk2, sub2, SS::pairs(sub2));
                 }
             }
             __syncthreads();
+            g++;
         }
     }
-    // ---- epilogue: vertical march of the last step
+    // ---- epilogue: vertical march of the last step, (nblocks - 1, last_subs - 1)
     if (role == 1) {
         float *prev = sbase + ((g + 2) % 3) * BUF;
-        VPASS(prev, nblocks - 1, S - 1)
+        if (last_subs >= S) { VPASS(prev, nblocks - 1, S - 1) }
+        if constexpr (S > 1) { if (last_subs == 1) { VPASS(prev, nblocks - 1, 0) } }
+        if constexpr (S > 2) { if (last_subs == 2) { VPASS(prev, nblocks - 1, 1) } }
+        if constexpr (S > 3) { if (last_subs == 3) { VPASS(prev, nblocks - 1, 2) } }
     }
 #undef VPASS
 }

@@ -93,7 +93,7 @@ struct Options {
     int march = 1;           // marching blur for large planes (0: tiled blur everywhere)
     int team = 1;            // team form of the marching blur (0: one-block form)
     int march_nt = 128;      // threads per workgroup of the one-block form (64 or 128)
-    int march_wgs = 0;       // workgroups wanted by the one-block form (0: default)
+    int march_wgs = 0;       // workgroups wanted by the marching blur (0: 1024, 768 for 27 taps)
     int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
     int ori_blocks = 1024, ori_pad = 0;
     int desc_blocks = 2048, desc_pad = 0;    // descriptor launch: workgroups, bytes of dynamic LDS (residency throttle)
@@ -242,20 +242,34 @@ void launch_march_nt(const Options &opt, hipStream_t st, const void *in, float *
     hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT, DT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
 }
 
-// team form of the marching blur (blur_team_kernel): S sub-blocks per accumulator period, `wgs` workgroups wanted
+// team form of the marching blur (blur_team_kernel): S sub-blocks per accumulator period, `wgs` workgroups wanted.
+// A segment (grid row) outputs rows_out = ceil(H / segments) rows and marches rows_out + N - 1 rows rounded up to whole
+// sub-blocks (nblocks - 1 full periods + last_subs sub-blocks), so the workgroup count is the one asked for -- 768 for
+// 27 taps on a 4096^2 plane, 3 per CU -- instead of one quantised by segment heights in multiples of N rows (608: 2.4 per CU).
 template <int N, bool NORM, int S, int DT = 0>
-void launch_team(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs) {
+void launch_team(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs) {
     using G = March2Geom<N, 128, S>;
+    using SS = SubSplit<N, S>;
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
+    if (opt.march_wgs > 0) wgs = opt.march_wgs;
     const int gx = (W + G::TX - 1) / G::TX;
-    const int want_segments = (wgs + gx - 1) / gx;
-    const int rows = (H + want_segments - 1) / want_segments;
-    int nblocks = (rows + (N - 1) + N - 1) / N;
-    if (nblocks < 3) nblocks = 3;
-    const int rows_out = nblocks * N - (N - 1);
-    dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
-    hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+    int gy = wgs / gx;
+    if (gy < 1) gy = 1;
+    if (gy > H) gy = H;
+    int rows_out = (H + gy - 1) / gy;
+    if (rows_out < 2 * N + 1) rows_out = 2 * N + 1;     // small planes: at most one third of the marched rows is warm-up
+    gy = (H + rows_out - 1) / rows_out;
+    // rows marched by b full periods + m sub-blocks of the next one
+    auto covered = [](int b, int m) { int r = b * N; for (int q = 0; q < m; q++) r += SS::rows(q); return r; };
+    const int need = rows_out + N - 1;
+    const int b = need / N;
+    int m = 0;
+    while (covered(b, m) < need) m++;                // m <= S
+    const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
+                       rows_out, ta, mm);
 }
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
@@ -269,7 +283,7 @@ void launch_march_t(const Options &opt, hipStream_t st, const void *in, float *o
         return;
     }
     constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
-    launch_team<N, NORM, S, DT>(st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024);
+    launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024);
 }
 
 // returns false when no tiled instantiation exists for this tap count

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r02
+# -> gpurun_out/round_<tag>/ ; copy what should be judged into profiles/<tag>/.
+TAG=${1:-r02}
+R=$(pwd)
+OUT=$R/gpurun_out/round_$TAG
+rm -rf $OUT; mkdir -p $OUT
+bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1
+cp gpurun_out/prof_$TAG/summary.txt $OUT/rocprofv3_summary.txt
+cp gpurun_out/prof_$TAG/kt/*kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv 2>/dev/null
+cp gpurun_out/prof_$TAG/bench_under_rocprof.json $OUT/ 2>/dev/null
+cp gpurun_out/prof_$TAG/blur_traffic.json $OUT/ 2>/dev/null
+python tools/stage_profile.py 4096 white 3 > $OUT/stage_white4096.txt 2>&1
+python tools/stage_profile.py 4096 smooth 0 > $OUT/stage_smooth4096.txt 2>&1
+bash tools/dev/trace_gaps.sh > $OUT/timeline_white4096.txt 2>&1
+for k in descriptor_kernel orientation_kernel extrema_kernel; do bash tools/dev/pmc_kernel.sh $k > $OUT/pmc_$k.txt 2>&1; done
+python tools/bench_match.py > $OUT/match_100k.txt 2>&1
+python tools/dev/quick_smooth.py > $OUT/configs.txt 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --config c4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2>> $OUT/bench.err
+ls -la $OUT
+# keep what travels back small (gpurun merges at most 64 MiB): the raw CSVs stay on the box
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_* gpurun_out/trace_gaps

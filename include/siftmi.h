@@ -208,6 +208,9 @@ int siftmi_stage_local_maxmin(int32_t device_id, const float *blurs, int32_t W, 
 /* candidates (n,4) -> refined (peak,row,col,sigma) + detection scale, holes removed */
 int siftmi_stage_interp(int32_t device_id, const float *blurs, int32_t W, int32_t H, const float *cand, int64_t n,
                         const siftmi_params *params, float *out, int32_t *out_scale, int64_t *n_out);
+/* `compact` (openCL/algebra.cl:57-84, host side plan.py:758-795): rows [start, end) of kps (n,4) whose row field is not
+ * -1 are moved up to follow the first `start` rows; out receives *n_out rows (start + survivors), survivors unordered */
+int siftmi_stage_compact(int32_t device_id, const float *kps, int64_t n, int64_t start, int64_t end, float *out, int64_t *n_out);
 int siftmi_stage_gradient(int32_t device_id, const float *img, float *grad, float *ori, int32_t W, int32_t H);
 /* refined (n,4)+scale -> oriented (x,y,sigma*oct,angle)+scale, extras appended (capacity rows) */
 int siftmi_stage_orientation(int32_t device_id, const float *blurs, int32_t W, int32_t H, int32_t octsize,

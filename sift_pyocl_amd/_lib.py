@@ -84,6 +84,7 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "siftmi_stage_interp": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                       C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "siftmi_stage_compact": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "siftmi_stage_gradient": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "siftmi_stage_orientation": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                            C.c_void_p, C.c_int64, C.POINTER(Params), C.c_void_p, C.c_void_p,

@@ -244,6 +244,21 @@ __global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H,
     }
 }
 
+// Stand-alone compaction (stage replay of algebra.cl:57-84 as called at plan.py:758-795): entries [start, end) of `in`
+// whose row (s1) is not -1 are appended to `out` from *counter on, in no particular order -- the reference does not
+// guarantee one either.  The hot path never runs this: its refinement appends survivors directly (refine_kernel).
+// The append is convergent, so one atomic per wave reaches the counter (the compiler's atomic optimizer).
+__global__ void compact_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int *__restrict__ counter,
+                               int start, int end, int capacity) {
+    for (int i = start + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const float4 k = in[i];
+        if (k.y != -1.0f) {
+            const int slot = atomicAdd(counter, 1);
+            if (slot < capacity) out[slot] = k;
+        }
+    }
+}
+
 // DoG plane (stage replay of algebra.cl:18-37 as called at plan.py:619-623)
 __global__ void dog_kernel(const float *__restrict__ a, const float *__restrict__ bnext, float *__restrict__ out, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -1644,6 +1644,26 @@ int siftmi_stage_interp(int32_t dev, const float *blurs, int32_t W, int32_t H, c
     return SIFTMI_OK;
 }
 
+int siftmi_stage_compact(int32_t dev, const float *kps, int64_t n, int64_t start, int64_t end, float *out, int64_t *n_out) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    if (!n_out || start < 0 || end < start || end > n) return fail(SIFTMI_EINVAL, "bad range");
+    DevBuf a, o, cnt;
+    if ((rc = a.upload(kps, (size_t)n * 16)) || (rc = o.alloc((size_t)n * 16)) || (rc = cnt.alloc(16))) return rc;
+    // the reference compacts in place of a second buffer that starts as a copy of the head: entries below `start` stay
+    HIPCHK(hipMemcpy(o.p, a.p, (size_t)start * 16, hipMemcpyDeviceToDevice));
+    const int first = (int)start;
+    HIPCHK(hipMemcpy(cnt.p, &first, 4, hipMemcpyHostToDevice));
+    if (end > start)
+        hipLaunchKernelGGL(compact_kernel, dim3(grid_for(end - start, 256, 1024)), dim3(256), 0, 0, (const float4 *)a.as<float4>(),
+                           o.as<float4>(), cnt.as<int>(), (int)start, (int)end, (int)n);
+    if ((rc = stage_end())) return rc;
+    int count = 0;
+    HIPCHK(hipMemcpy(&count, cnt.p, 4, hipMemcpyDeviceToHost));
+    if (count > 0) HIPCHK(hipMemcpy(out, o.p, (size_t)count * 16, hipMemcpyDeviceToHost));
+    *n_out = count;
+    return SIFTMI_OK;
+}
+
 int siftmi_stage_gradient(int32_t dev, const float *img, float *grad, float *ori, int32_t W, int32_t H) {
     int rc = stage_begin(dev); if (rc) return rc;
     const size_t N = (size_t)W * H;

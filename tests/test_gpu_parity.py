@@ -130,6 +130,21 @@ def test_division_by_reciprocal_is_the_ieee_quotient(siftlib):
 
 
 # ----------------------------------------------------------------------------- stages
+def test_compact_stage(siftlib, oracle):
+    """stand-alone `compact` (algebra.cl:57-84): the head [0, start) stays, the survivors of [start, end) follow in any order"""
+    rng = np.random.default_rng(4)
+    n, start, end = 5000, 700, 4600
+    kps = rng.random((n, 4), dtype=np.float32) * 100
+    kps[rng.random(n) < 0.6] = -1.0
+    out = np.empty_like(kps)
+    m = C.c_int64(0)
+    assert siftlib.siftmi_stage_compact(0, _p(kps), n, start, end, _p(out), C.byref(m)) == 0
+    want, count = oracle.compact(kps, start, end)
+    assert m.value == count
+    assert np.array_equal(out[:start], kps[:start])
+    assert np.array_equal(sort_rows(out[start:count]), sort_rows(want[start:count]))
+
+
 def test_gaussian_taps(siftlib, oracle):
     for sigma, size in [(1.5198684, 15), (1.2262735, 11), (1.5450078, 15), (1.9465878, 17), (2.452547, 21), (3.0900156, 27),
                         (3.0, 28), (0.7, 7)]:

@@ -25,7 +25,8 @@
 //     front to back (four values per LDS read): ascending lane == raster order.
 //  4. Normalise / clamp 0.2 / renormalise / quantise with the reference's sequential 128-term sums.
 //
-// Windows with more than 2 * SIFT_DESC_MAXRAD + 1 rows (init_sigma > ~4) are left to descriptor_stream_kernel.
+// Windows with more than 2 * SIFT_DESC_MAXRAD + 1 rows are left to descriptor_stream_kernel (a plan cannot produce them:
+// the 64-tap limit of the blur schedule caps init_sigma at 4.08, i.e. 247 rows; the stage entry point can).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
 
 // ------------------------------------------------------------------------------------------
 // Descriptor, streaming form: ONE WAVEFRONT per oriented keypoint, no workgroup barriers (keypoints_cpu.cl:36-161).
-// Handles windows of any size; since round 2 only used when a plan's windows can exceed SIFT_DESC_MAXRAD rows
-// (init_sigma > ~4) -- k_descriptor.hpp holds the row-interval form used otherwise.
+// Handles windows of any size; since round 2 only used for keypoint lists handed to the stage entry point whose windows
+// exceed 2 * SIFT_DESC_MAXRAD + 1 rows, or on request (option "desc_stream") -- k_descriptor.hpp holds the row-interval form.
 //
 //  1. The (2R+1)^2 raster scan is filtered to the samples that fall inside the rotated 5x5-cell
 //     window by an ORDER-PRESERVING compaction (wave ballot + popcount prefix) into a small LDS

@@ -52,3 +52,42 @@ def test_unknown_option_and_fixed_fields(siftlib):
         plan.set_option("no_such_option", 1)
     plan.set_option("overlap", 0)
     plan.set_option("overlap", 1)
+
+
+def test_descriptor_kernel_forms_agree(siftlib, oracle):
+    """The row-interval descriptor kernel (default), the streaming form forced through the option, and plans with the
+    widest windows the 64-tap limit of the blur schedule allows (init_sigma = 4.0: up to 243 window rows, still inside the
+    row tables) must all equal the oracle bit for bit."""
+    import sift_pyocl_amd as sp
+    img = smooth_noise((420, 510), seed=23, sigma=2.5)
+    want = oracle.keypoints(img)
+    plan = sp.SiftPlan(template=img)
+    assert_same_keypoints(plan.keypoints(img), want, "row-interval form")
+    plan.set_option("desc_stream", 1)
+    assert_same_keypoints(plan.keypoints(img), want, "streaming form")
+    plan.set_option("desc_stream", 0)
+    plan.pinned_results = False                                  # plain numpy result + device-to-host copy
+    assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
+    for init_sigma in (3.0, 4.0):
+        big = sp.SiftPlan(template=img, init_sigma=init_sigma)
+        got = big.keypoints(img)
+        assert len(got) > 10
+        assert_same_keypoints(got, oracle.keypoints(img, par=oracle.default_params(init_sigma=init_sigma)), "init_sigma %g" % init_sigma)
+        big.set_option("desc_stream", 1)
+        assert_same_keypoints(big.keypoints(img), got, "init_sigma %g, streaming form" % init_sigma)
+
+
+def test_result_arrays_outlive_the_plan_and_recycle(siftlib):
+    """Results are views of pinned blocks from the library's pool: they must stay valid after later calls and after the
+    plan is gone, and dropping them must hand the blocks back (no growth over many calls)."""
+    import gc
+    import sift_pyocl_amd as sp
+    img = smooth_noise((256, 300), seed=5)
+    plan = sp.SiftPlan(template=img)
+    first = plan.keypoints(img)
+    keep = first.copy()
+    others = [plan.keypoints(np.roll(img, s, axis=1)) for s in range(1, 6)]
+    assert np.array_equal(first.view(np.uint8), keep.view(np.uint8))      # not overwritten by the later calls
+    del plan, others
+    gc.collect()
+    assert np.array_equal(first.view(np.uint8), keep.view(np.uint8))

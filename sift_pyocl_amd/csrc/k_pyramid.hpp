@@ -609,6 +609,13 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
 
     auto prefetch = [&](int blk, int sub, int np) {
         const int v0 = ys - G::C + blk * N + sub * SS::RB;
+        if (BLUR_ABL & 4) {
+#pragma unroll
+            for (int rp = 0; rp < G::NPS; rp++) { pa[rp] = (f32x2){1.f, 2.f}; pb[rp] = (f32x2){3.f, 4.f}; }
+#pragma unroll
+            for (int u = 0; u < G::NB; u++) ph[u] = (f32x2){5.f, 6.f};
+            return;
+        }
         if (v0 >= 0 && v0 + 2 * np <= H) {
             unsigned oa = ((unsigned)v0 * (unsigned)W + (unsigned)gx_a) * 4u;
             unsigned ob = ((unsigned)v0 * (unsigned)W + (unsigned)gx_b) * 4u;
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
     };
     // horizontal pass of one sub-block (np row pairs) in place, by the HW waves of the H team (one wave per row pair)
     auto hpass = [&](float *s, int np) {
-        for (int task = tid; task < np * (NT / 2); task += 64 * HW) {
+        for (int task = tid; task < ((BLUR_ABL & 1) ? 0 : np * (NT / 2)); task += 64 * HW) {
             const int rp = task / (NT / 2), t4 = task % (NT / 2);
             float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
             f32x2 w[G::NW];
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
                     if (2 * rp + half < nrows_) {                                                            \
                         const int kk = (sub_) * SS::RB + 2 * rp + half;                                      \
                         const f32x2 h = half ? hv.zw : hv.xy;                                                \
-                        _Pragma("unroll") for (int k = 0; k < (N + 1) / 2; k++) {                            \
+                        _Pragma("unroll") for (int k = 0; k < ((BLUR_ABL & 2) ? 1 : (N + 1) / 2); k++) {     \
                             const f32x2 t2 = {taps.t[k], taps.t[k]};                                         \
                             const f32x2 prod = h * t2;                                                       \
                             const int slot_a = (kk - k + N) % N, slot_b = (kk - (N - 1 - k) + N) % N;        \
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
                         }                                                                                    \
                         const int done = (kk + 1) % N;                                                       \
                         const int y = ybase_ + kk;                                                           \
-                        if (y >= ys && y < yend) {                                                           \
+                        if (y >= ys && y < yend && !((BLUR_ABL & 8) && acc[done].x != 12345.678f)) {        \
                             if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];                     \
                             else { if (gxo < W) optr[0] = acc[done].x; if (gxo + 1 < W) optr[1] = acc[done].y; } \
                         }                                                                                    \

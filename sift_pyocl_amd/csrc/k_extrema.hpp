@@ -17,8 +17,16 @@ struct BlurPlanes { const float *p[6]; };
 // 3x3x3 extremum test restated: v is kept as a maximum iff v > 0 and no sample of the 27 is
 // strictly greater, i.e. v >= max27 (image.cl:156-167); likewise for minima.  max27 is separable:
 // max over the 3 scales, then 3 columns (neighbour lanes), then 3 rows (rolling registers).
-// One wave scans a strip 62 columns wide (lanes 0 and 63 are halo) and ROWS_PER_STRIP rows high.
+// One wave scans a strip 62 columns wide (lanes 0 and 63 are halo) and `rows` rows high.  A strip is a serial march
+// (one row of loads in flight ahead of the row being tested), so its height is the latency of the launch: 32 rows on
+// large planes, fewer where 32-row strips would leave most SIMDs without a wave (extrema_strip_rows).
 #define SIFT_EXT_ROWS 32
+inline int extrema_strip_rows(int W, int H, int border) {
+    const int nx = (W - 2 * border + 61) / 62;
+    int rows = SIFT_EXT_ROWS;
+    while (rows > 4 && (int64_t)nx * ((H - 2 * border + rows - 1) / rows) < 12288) rows >>= 1;   // measured: 4096^2 -> 16, 2048^2 and below -> 4
+    return rows;
+}
 
 __device__ __forceinline__ float dog_at(const BlurPlanes &b, int s, size_t pos) { return b.p[s][pos] - b.p[s + 1][pos]; }
 
@@ -33,33 +41,31 @@ __device__ __forceinline__ float dog_at(const BlurPlanes &b, int s, size_t pos) 
 #define SIFT_EXT_WAVES 5      // 92 VGPRs without scratch; forcing 6 waves (80 VGPRs) now spills 11 registers in the row loop: 0.18 ms instead of 0.10
 #endif
 #define SIFT_EXT_BUF 128          // candidates a wave parks before reserving slots (a row adds at most 3 x 62)
-struct ExtWaveLds { float4 buf[SIFT_EXT_BUF + 192]; };
+template <int BUF> struct ExtWaveLdsT { float4 buf[BUF + 192]; };
+using ExtWaveLds = ExtWaveLdsT<SIFT_EXT_BUF>;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, double contrast,
-                                                      float edth, float4 *__restrict__ cand,
-                                                      int *__restrict__ counter, int capacity) {
-    __shared__ ExtWaveLds lds_all[4];
-    __shared__ int s_pending[4], s_base;
+// parked candidates [0, count) of a wave -> cand[slot ...]
+template <int BUF>
+__device__ __forceinline__ void ext_store_pending(const ExtWaveLdsT<BUF> &L, float4 *__restrict__ cand, int capacity, int slot, int count, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < count; e += 64)
+        if (slot + e < capacity) cand[slot + e] = L.buf[e];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wave marches strip (sx, sy) (all 64 lanes enter; an inactive wave does nothing but keeps the wave-wide operations
+// convergent).  Candidates are parked in L.buf; `pending` (wave uniform) counts them; a full buffer is flushed through
+// one atomicAdd.  What is still parked on return is the caller's to flush.
+template <int BUF>
+__device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H, int border, int rows, bool active, int sx, int sy,
+                                              double contrast, float edth, float4 *__restrict__ cand, int *__restrict__ counter,
+                                              int capacity, ExtWaveLdsT<BUF> &L, int &pending) {
     const int lane = threadIdx.x & 63;
-    ExtWaveLds &L = lds_all[threadIdx.x >> 6];
-    const int nx = (W - 2 * border + 61) / 62;
-    const int ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
-    const int sx = active ? wid % nx : 0, sy = active ? wid / nx : 0;
     const int x = border + sx * 62 + lane - 1;
     const int xc = min(max(x, 0), W - 1);
     const bool col_ok = (lane >= 1) && (lane <= 62) && (x < W - border);
-    const int ya = border + sy * SIFT_EXT_ROWS;
-    const int yb = active ? min(ya + SIFT_EXT_ROWS, H - border) : ya - 2;
-
-    int pending = 0;                                     // candidates parked in L.buf (wave uniform)
-    auto store_pending = [&](int slot, int count) {
-        __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < count; e += 64)
-            if (slot + e < capacity) cand[slot + e] = L.buf[e];
-        __builtin_amdgcn_wave_barrier();
-    };
+    const int ya = border + sy * rows;
+    const int yb = active ? min(ya + rows, H - border) : ya - 2;
 
     float hM[3][3], hm[3][3];   // [row slot][scale]: horizontal+scale max / min for rows y-2, y-1, y
     float ctr[3] = {0.f, 0.f, 0.f}, ctr_next[3];
@@ -140,15 +146,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WA
                 pending += __popcll(m);
             }
         }
-        if (pending > SIFT_EXT_BUF) {                                 // wave uniform: reserve slots for the whole buffer
+        if (pending > BUF) {                                 // wave uniform: reserve slots for the whole buffer
             int slot = 0;
             if (lane == 0) slot = atomicAdd(counter, pending);
-            store_pending(__shfl(slot, 0), pending);
+            ext_store_pending(L, cand, capacity, __shfl(slot, 0), pending, lane);
             pending = 0;
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) ctr[k] = ctr_next[k];
     }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
+                                                      float edth, float4 *__restrict__ cand,
+                                                      int *__restrict__ counter, int capacity) {
+    __shared__ ExtWaveLds lds_all[4];
+    __shared__ int s_pending[4], s_base;
+    const int lane = threadIdx.x & 63;
+    ExtWaveLds &L = lds_all[threadIdx.x >> 6];
+    const int nx = (W - 2 * border + 61) / 62;
+    const int ny = (H - 2 * border + rows - 1) / rows;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
+    int pending = 0;                                     // candidates parked in L.buf (wave uniform)
+    extrema_strip(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand, counter, capacity, L, pending);
     // ---- what is left leaves with one atomicAdd per workgroup
     if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
     __syncthreads();
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WA
         const int w = threadIdx.x >> 6;
         int slot = s_base;
         for (int q = 0; q < w; q++) slot += s_pending[q];
-        store_pending(slot, pending);
+        ext_store_pending(L, cand, capacity, slot, pending, lane);
     }
 }
 
@@ -169,15 +190,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WA
 // algebra.cl:57-84).  One thread per candidate, grid-stride over the device-side count.
 // Output: (peak, row, col, sigma) and the integer detection scale (the reference keeps the
 // scale implicitly as the loop variable of plan.py:626).
-__global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H, const float4 *__restrict__ cand,
-                                                     const int *__restrict__ n_cand, int cand_capacity,
-                                                     float peak_thresh, float init_sigma,
-                                                     float4 *__restrict__ kp, int *__restrict__ kp_aux,
-                                                     int *__restrict__ n_kp, int kp_capacity, int oct,
-                                                     int *__restrict__ overflow) {
-    const int n = min(*n_cand, cand_capacity);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > cand_capacity && overflow) *overflow = 1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void refine_candidates(const BlurPlanes &b, int W, int H, const float4 *__restrict__ cand, int n,
+                                                  float peak_thresh, float init_sigma, float4 *__restrict__ kp,
+                                                  int *__restrict__ kp_aux, int *__restrict__ n_kp, int kp_capacity, int oct,
+                                                  int first, int stride) {
+    for (int i = first; i < n; i += stride) {
         const float4 k = cand[i];
         int r = (int)k.y, c = (int)k.z;
         const int scale = (int)k.w;
@@ -242,6 +259,18 @@ __global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H,
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H, const float4 *__restrict__ cand,
+                                                     const int *__restrict__ n_cand, int cand_capacity,
+                                                     float peak_thresh, float init_sigma,
+                                                     float4 *__restrict__ kp, int *__restrict__ kp_aux,
+                                                     int *__restrict__ n_kp, int kp_capacity, int oct,
+                                                     int *__restrict__ overflow) {
+    const int n = min(*n_cand, cand_capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > cand_capacity && overflow) *overflow = 1;
+    refine_candidates(b, W, H, cand, n, peak_thresh, init_sigma, kp, kp_aux, n_kp, kp_capacity, oct,
+                      blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // Stand-alone compaction (stage replay of algebra.cl:57-84 as called at plan.py:758-795): entries [start, end) of `in`

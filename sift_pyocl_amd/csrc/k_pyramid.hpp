@@ -203,8 +203,8 @@ __global__ void convert_rgb_kernel(const uint8_t *__restrict__ in, float *__rest
 // the reference's: acc = 0; acc = acc + in[x-c+j] * taps[N-1-j], j ascending, no FMA.
 template <int N> struct TapsArg { float t[N]; };
 
-template <int N> struct BlurGeom {
-    static constexpr int TX = 128, TY = 64;
+template <int N, int TX_ = 128, int TY_ = 64> struct BlurGeom {
+    static constexpr int TX = TX_, TY = TY_;
     static constexpr int C = (N & 1) ? N / 2 : N / 2 - 1;   // convolution.cl:27-37
     static constexpr int ROWS = TY + N - 1;
     static constexpr int COLS = TX + N - 1;
@@ -219,11 +219,16 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
     return min(max(i, 0), n - 1);   // clamp only matters for lanes whose output is masked
 }
 
-template <int N, bool NORM, int DT = 0>
+// TX x TY = 128 x 64 is the throughput shape; planes too small to give every CU a 128 x 64 tile use 64 x 32 or
+// 32 x 16 tiles (VR = rows per vertical task: 8, or 4 to spread the small tiles' vertical pass over more lanes).
+// A pyramid of a small frame is a chain of short launches, so it is the latency of one workgroup that matters there.
+template <int N, bool NORM, int DT = 0, int TX = 128, int TY = 64, int VR = 8>
 __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                       int W, int H, TapsArg<N> taps,
                                                       const uint32_t *__restrict__ mm) {
-    using G = BlurGeom<N>;
+    using G = BlurGeom<N, TX, TY>;
+    static_assert(TX % 4 == 0 && 64 % (TX / 4) == 0, "the H tasks of one row must sit in one wave");
+    static_assert(TY % VR == 0, "vertical tasks tile the rows");
     extern __shared__ float4 smem4[];
     float *s = reinterpret_cast<float *>(smem4);
     const int tid = threadIdx.x;
@@ -244,8 +249,9 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ i
     __syncthreads();
 
     // ---- 2. horizontal pass, in place -------------------------------------------------------
-    for (int task = tid; task < G::ROWS * 32; task += 256) {
-        const int row = task >> 5, t = task & 31;
+    constexpr int HT = TX / 4;   // 4-output tasks per row
+    for (int task = tid; task < G::ROWS * HT; task += 256) {
+        const int row = task / HT, t = task - row * HT;
         float *rowp = s + row * G::PITCH + 4 * t;
         float w[G::NW];
 #pragma unroll
@@ -262,37 +268,38 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ i
             a2 = a2 + w[q + 2] * tp;
             a3 = a3 + w[q + 3] * tp;
         }
-        // All lanes of this wave have issued their reads (same row lives in one half-wave and LDS
-        // executes a wave's operations in order); keep the compiler from moving the store up.
+        // All tasks of a row sit in one wave (64 % HT == 0) and LDS executes a wave's operations in order: every
+        // lane has issued its reads before any lane stores.  Keep the compiler from moving the store up.
         __builtin_amdgcn_wave_barrier();
         *reinterpret_cast<float4 *>(rowp) = make_float4(a0, a1, a2, a3);
     }
     __syncthreads();
 
-    // ---- 3. vertical pass --------------------------------------------------------------------
-    const int c2 = (tid & 63) * 2, q4 = tid >> 6;
-    const int gx = x0 + c2;
+    // ---- 3. vertical pass: a task = 2 adjacent columns x VR rows --------------------------------
+    constexpr int CP = TX / 2;
 #pragma unroll 1
-    for (int chunk = 0; chunk < 2; chunk++) {
-        const int r0 = q4 * 16 + chunk * 8;
-        float2 w[8 + N - 1];
+    for (int task = tid; task < CP * (TY / VR); task += 256) {
+        const int rg = task / CP, c2 = (task - rg * CP) * 2;
+        const int r0 = rg * VR;
+        const int gx = x0 + c2;
+        float2 w[VR + N - 1];
 #pragma unroll
-        for (int k = 0; k < 8 + N - 1; k++)
+        for (int k = 0; k < VR + N - 1; k++)
             w[k] = *reinterpret_cast<const float2 *>(s + (r0 + k) * G::PITCH + c2);
-        float2 acc[8];
+        float2 acc[VR];
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc[i] = make_float2(0.f, 0.f);
+        for (int i = 0; i < VR; i++) acc[i] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < N; q++) {
             const float tp = taps.t[N - 1 - q];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < VR; i++) {
                 acc[i].x = acc[i].x + w[i + q].x * tp;
                 acc[i].y = acc[i].y + w[i + q].y * tp;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < VR; i++) {
             const int gy = y0 + r0 + i;
             if (gy < H) {
                 float *o = out + (size_t)gy * W + gx;

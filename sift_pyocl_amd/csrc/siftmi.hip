@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -25,6 +26,7 @@
 #include "k_align.hpp"
 #include "k_match.hpp"
 #include "k_pyramid.hpp"
+#include "k_tail.hpp"
 #include "siftmath.hpp"
 
 using namespace siftk;
@@ -99,6 +101,9 @@ struct Options {
     int desc_blocks = 2048, desc_pad = 0;    // descriptor launch: workgroups, bytes of dynamic LDS (residency throttle)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
+    int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
+    int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
+    int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
     int chain0 = 1;          // octave 0 end to end on the pyramid stream, later octaves' pyramids on the second chain
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
@@ -153,6 +158,8 @@ struct siftmi_plan {
     uint32_t *mm = nullptr;
     Counters *cnt = nullptr;
     float4 *cand = nullptr;
+    float4 *tail_cand = nullptr;   // candidate lists of octave_tail_kernel: SIFT_TAIL_MAX_OCT x tail_cand_cap
+    int tail_cand_cap = 0;
     float4 *kp = nullptr;
     int *kp_scale = nullptr;
     float4 *okp = nullptr;
@@ -168,6 +175,7 @@ struct siftmi_plan {
     hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_last_b = nullptr;
     float last_min = 0, last_max = 0;
     int64_t last_count = 0;
+    size_t tail_lds_set = 64 * 1024;   // dynamic LDS limit already granted to octave_tail_kernel
     std::vector<void *> allocs;
 
     template <class T> int alloc(T **p, size_t nbytes) {
@@ -215,13 +223,27 @@ int compute_schedule(siftmi_plan *p) {
     return SIFTMI_OK;
 }
 
+template <int N, bool NORM, int DT, int TX, int TY, int VR>
+void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, const TapsArg<N> &ta, const uint32_t *mm) {
+    using G = BlurGeom<N, TX, TY>;
+    dim3 grid((unsigned)((W + TX - 1) / TX), (unsigned)((H + TY - 1) / TY));
+    hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT, TX, TY, VR>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
+}
+
+// Tile shape.  Planes that reach this kernel are narrower than 1024 columns or shorter than 512 rows (larger ones take
+// the marching kernels); on all of them the 32 x 16 tile measured fastest (whole call, MI355X: 512^2 0.75 / 0.52 /
+// 0.44 ms and 1020^2 0.90 / 0.63 / 0.53 ms for 128x64 / 64x32 / 32x16), so the larger shapes are kept for experiments.
+inline int blur_tile_class(const Options &opt, int, int) { return opt.tile > 0 ? opt.tile : 3; }
+
 template <int N, bool NORM, int DT = 0>
-void launch_blur_t(hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
-    using G = BlurGeom<N>;
+void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
-    dim3 grid((unsigned)((W + G::TX - 1) / G::TX), (unsigned)((H + G::TY - 1) / G::TY));
-    hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
+    switch (blur_tile_class(opt, W, H)) {
+        case 1: launch_blur_geom<N, NORM, DT, 128, 64, 8>(st, in, out, W, H, ta, mm); break;
+        case 2: launch_blur_geom<N, NORM, DT, 64, 32, 8>(st, in, out, W, H, ta, mm); break;
+        default: launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm); break;
+    }
 }
 
 template <int N, bool NORM, int NT, int DT = 0>
@@ -287,11 +309,15 @@ void launch_march_t(const Options &opt, hipStream_t st, const void *in, float *o
 }
 
 // returns false when no tiled instantiation exists for this tap count
+// The marching kernels amortise their prologue over long strips; measured cross-over with the 32 x 16 tile kernel
+// is near 1400^2 (whole call 0.607 vs 0.609 ms; 1024^2 0.555 vs 0.529, 2048^2 0.732 vs 0.779).
+inline bool march_plane(int W, int H) { return W >= 1024 && H >= 512 && (int64_t)W * H >= 1400 * 1400; }
+
 template <bool NORM>
 bool launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
     bool symmetric = true;
     for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
-    if (W >= 1024 && H >= 512 && symmetric && opt.march) {
+    if (march_plane(W, H) && symmetric && opt.march) {
         switch (t.n) {
             case 11: launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
             case 15: launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
@@ -302,11 +328,11 @@ bool launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, floa
         }
     }
     switch (t.n) {
-        case 11: launch_blur_t<11, NORM>(st, in, out, W, H, t.t, mm); return true;
-        case 15: launch_blur_t<15, NORM>(st, in, out, W, H, t.t, mm); return true;
-        case 17: launch_blur_t<17, NORM>(st, in, out, W, H, t.t, mm); return true;
-        case 21: launch_blur_t<21, NORM>(st, in, out, W, H, t.t, mm); return true;
-        case 27: launch_blur_t<27, NORM>(st, in, out, W, H, t.t, mm); return true;
+        case 11: launch_blur_t<11, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+        case 15: launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+        case 17: launch_blur_t<17, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+        case 21: launch_blur_t<21, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+        case 27: launch_blur_t<27, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
         default: return false;
     }
 }
@@ -336,10 +362,10 @@ bool taps_symmetric(const Taps &t) {
 template <int DT>
 bool launch_init_blur_dt(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
     if (t.n != 15) return false;
-    if (W >= 1024 && H >= 512 && taps_symmetric(t) && opt.march)
+    if (march_plane(W, H) && taps_symmetric(t) && opt.march)
         launch_march_t<15, true, DT>(opt, st, in, out, W, H, t.t, mm);
     else
-        launch_blur_t<15, true, DT>(st, in, out, W, H, t.t, mm);
+        launch_blur_t<15, true, DT>(opt, st, in, out, W, H, t.t, mm);
     return true;
 }
 
@@ -406,12 +432,13 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
     const int border = p->par.border_dist;
     const int kcap = (int)p->kpsize;
     if (W > 2 * border && H > 2 * border) {
-        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
+        const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border);
+        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
         const int blocks = (nx * ny + 3) / 4;
         const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
         snprintf(lab, sizeof lab, "local_maxmin %d", oct);
         Scope sc(p, lab, false, 0, st);
-        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border,
+        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
                            contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap);
     }
     {
@@ -421,6 +448,52 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
                            (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
                            p->kp_scale, &p->cnt->n_kp, kcap, oct, &p->cnt->overflow);
     }
+}
+
+// First octave of the run that octave_tail_kernel takes (k_tail.hpp), or n_oct when it takes none: octaves >= 1 whose
+// planes are small enough to sit in LDS, all the way down to the last one.
+int tail_first_octave(const siftmi_plan *p) {
+    if (!p->opt.tail || p->profile || p->n_oct < 2) return p->n_oct;
+    for (int s = 0; s < 5; s++) {
+        const int n = p->taps[s].n;
+        if (n != 11 && n != 15 && n != 17 && n != 21 && n != 27) return p->n_oct;
+    }
+    const int last = p->n_oct - 1;
+    if (p->ow[(size_t)last] < 14 || p->oh[(size_t)last] < 14) return p->n_oct;
+    int first = p->n_oct;
+    for (int o = last; o >= 1; o--) {
+        const int W = p->ow[(size_t)o], H = p->oh[(size_t)o];
+        if ((int64_t)W * H > SIFT_TAIL_MAX_PIXELS || W > 128 || H > 128 || last - o + 1 > SIFT_TAIL_MAX_OCT) break;
+        first = o;
+    }
+    return first;
+}
+
+// octaves [first, n_oct): pyramid + detection in one launch
+int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
+    TailArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = p->plane(first - 1, 3);
+    a.src_w = p->ow[(size_t)first - 1];
+    a.n = p->n_oct - first;
+    for (int k = 0; k < a.n; k++) {
+        const int oct = first + k;
+        TailOctave &o = a.o[k];
+        for (int s = 0; s < 6; s++) o.plane[s] = p->plane(oct, s);
+        o.W = p->ow[(size_t)oct]; o.H = p->oh[(size_t)oct]; o.oct = oct;
+        o.edth = ((1 << oct) <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
+    }
+    for (int s = 0; s < 5; s++) { a.taps[s] = p->taps[s].dev; a.ntaps[s] = p->taps[s].n; }
+    const size_t lds = tail_lds_bytes(a.o[0].W, a.o[0].H);
+    if (lds > p->tail_lds_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&octave_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        p->tail_lds_set = lds;
+    }
+    const int kcap = (int)p->kpsize;
+    hipLaunchKernelGGL(octave_tail_kernel, dim3((unsigned)a.n), dim3(SIFT_TAIL_THREADS), lds, st, a, p->par.border_dist,
+                       contrast_threshold(p->par), p->par.peak_thresh, (float)p->par.init_sigma, p->tail_cand, p->tail_cand_cap,
+                       p->cnt->n_cand, p->cnt->tail_ready, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, &p->cnt->overflow);
+    return SIFTMI_OK;
 }
 
 // orientation + descriptor for every refined keypoint of one group of octaves
@@ -551,6 +624,9 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc) rc = p->alloc(&p->cnt, sizeof(Counters));
     if (!rc) p->mm = p->cnt->mm;   // device address of the min/max slots inside the counter block
     if (!rc) rc = p->alloc(&p->cand, (size_t)p->kpsize * sizeof(float4));
+    // a tail octave (<= SIFT_TAIL_MAX_PIXELS samples, 3 scales) cannot hold more candidates than this
+    p->tail_cand_cap = (int)std::min<int64_t>(p->kpsize, 3 * SIFT_TAIL_MAX_PIXELS);
+    if (!rc) rc = p->alloc(&p->tail_cand, (size_t)SIFT_TAIL_MAX_OCT * p->tail_cand_cap * sizeof(float4));
     if (!rc) rc = p->alloc(&p->kp, (size_t)p->kpsize * sizeof(float4));
     if (!rc) rc = p->alloc(&p->kp_scale, (size_t)p->kpsize * sizeof(int));
     if (!rc) rc = p->alloc(&p->okp, (size_t)p->kpsize * sizeof(float4));
@@ -632,6 +708,9 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
     else if (n == "chain0") o.chain0 = v != 0;
+    else if (n == "tile") o.tile = (int)v;
+    else if (n == "ext_rows") o.ext_rows = (int)v;
+    else if (n == "tail") o.tail = v != 0;
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
@@ -748,11 +827,26 @@ int enqueue_body(siftmi_plan *p) {
     // the round-1 layout: every pyramid on `stream`, octave 0's detection on `stream2`.)
     const bool two = p->overlap && p->n_oct > 0;
     const bool chain0 = two && p->opt.chain0;
+    const int tail_first = tail_first_octave(p);
     for (int oct = 0; oct < p->n_oct; oct++) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
         hipStream_t pyr = (chain0 && oct > 0) ? p->stream3 : p->stream;                     // builds this octave's planes
         hipStream_t dst = !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : p->stream3);   // consumes them
         if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
+        if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp), then the group's descriptors
+            if (two) {
+                if (pyr != dst) {
+                    HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
+                    HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
+                }
+                if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
+            }
+            int rc = launch_tail(p, oct, dst);
+            if (rc) return rc;
+            launch_describe_group(p, 1, dst);
+            if (two) HIPCHK(hipEventRecord(p->ev_grp1, dst));
+            break;
+        }
         if (oct > 0) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
@@ -1602,9 +1696,10 @@ int siftmi_stage_local_maxmin(int32_t dev, const float *blurs, int32_t W, int32_
     for (int s = 0; s < 6; s++) bp.p[s] = b.as<float>() + (size_t)s * N;
     const int border = par->border_dist;
     if (W > 2 * border && H > 2 * border) {
-        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + SIFT_EXT_ROWS - 1) / SIFT_EXT_ROWS;
+        const int rows = extrema_strip_rows(W, H, border);
+        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
         const float edth = (octsize <= 1) ? par->edge_thresh0 : par->edge_thresh;
-        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border,
+        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border, rows,
                            contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity);
     }
     if ((rc = stage_end())) return rc;

@@ -91,3 +91,26 @@ def test_result_arrays_outlive_the_plan_and_recycle(siftlib):
     del plan, others
     gc.collect()
     assert np.array_equal(first.view(np.uint8), keep.view(np.uint8))
+
+
+SMALL_SHAPES = [(512, 512), (300, 517), (129, 1000), (97, 97), (260, 131), (640, 480), (1030, 770)]
+
+
+@pytest.mark.parametrize("shape", SMALL_SHAPES)
+def test_small_frame_kernels_agree(siftlib, oracle, shape):
+    """Small planes take their own launch shapes -- 32 x 16 blur tiles, short extrema strips, and one launch for all
+    octaves of at most 64 x 64 samples (octave_tail_kernel, a workgroup per octave chained through plane 3).  Every
+    combination of those options must give the oracle's records bit for bit; odd sizes give the tail planes odd pitches."""
+    import sift_pyocl_amd as sp
+    img = smooth_noise(shape, seed=shape[0] + shape[1], sigma=2.0)
+    want = oracle.keypoints(img) if shape[0] * shape[1] <= 300 * 517 else None
+    plan = sp.SiftPlan(template=img)
+    base = plan.keypoints(img)
+    assert len(base) > 5
+    if want is not None:
+        assert_same_keypoints(base, want, "defaults vs oracle %r" % (shape,))
+    for opts in (dict(tail=0), dict(tail=0, tile=1, ext_rows=32), dict(tail=1, tile=2, ext_rows=8), dict(tail=1, overlap=0)):
+        other = sp.SiftPlan(template=img)
+        for name, value in opts.items():
+            other.set_option(name, value)
+        assert_same_keypoints(other.keypoints(img), base, "%r with %r" % (shape, opts))

@@ -86,7 +86,7 @@ int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsiz
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Names: "fused_convert", "overlap", "march",
- * "team", "march_nt", "march_wgs", "march_nb", "ori_blocks", "ori_pad", "desc_blocks", "desc_pad", "desc_stream", "mm_blocks", "chain0", "tile", "ext_rows", "tail", "spin",
+ * "team", "march_nt", "march_wgs", "march_nb", "ori_blocks", "ori_pad", "desc_blocks", "desc_pad", "desc_stream", "mm_blocks", "chain0", "tile", "ext_rows", "tail", "early_pyr", "spin",
  * "host_timing".  Unknown name -> SIFTMI_EINVAL. */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 /* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from
@@ -152,6 +152,8 @@ int siftmi_batch_info(const siftmi_batch *batch, int32_t *lanes, int64_t *bytes_
 /* light profiling of the lanes (level 1: one hipEvent pair around the full-resolution blur launches of every frame, as
  * siftmi_plan_create's profile = 1); siftmi_batch_blur_ms returns their sum over the frames of the last batch */
 int siftmi_batch_set_profile(siftmi_batch *batch, int32_t level);
+/* siftmi_plan_set_option on every lane of the batch */
+int siftmi_batch_set_option(siftmi_batch *batch, const char *name, int64_t value);
 int siftmi_batch_blur_ms(const siftmi_batch *batch, double *blur_ms, int64_t *blur_launches, double *blur_pixels);
 int siftmi_batch_keypoints(siftmi_batch *batch, const void *const *images, int32_t n_images, int32_t image_dtype,
                            int32_t images_are_device, int64_t *counts, int64_t *offsets, int64_t *total, int32_t *overflow);

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "siftmi_batch_destroy": (C.c_int, [C.c_void_p]),
     "siftmi_batch_set_params": (C.c_int, [C.c_void_p, C.c_void_p]),
     "siftmi_batch_set_profile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "siftmi_batch_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "siftmi_batch_blur_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "siftmi_batch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "siftmi_batch_keypoints": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64),

@@ -55,6 +55,10 @@ class BatchPlan(SiftPlan):
     def _destroy(self, L, h):
         L.siftmi_batch_destroy(h)
 
+    def set_option(self, name, value):
+        """SiftPlan.set_option on every lane (``siftmi_batch_set_option``); results never depend on an option."""
+        _lib.check(_lib.lib().siftmi_batch_set_option(self._handle, str(name).encode(), int(value)))
+
     def blur_times(self):
         """profile='light': hipEvent time, launches and pixels of the full-resolution blur launches of the last batch"""
         ms = C.c_double(); nl = C.c_int64(); px = C.c_double()

@@ -101,6 +101,7 @@ struct Options {
     int desc_blocks = 2048, desc_pad = 0;    // descriptor launch: workgroups, bytes of dynamic LDS (residency throttle)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
+    int early_pyr = 1;       // enqueue octave 1's pyramid before octave 0's detection / description
     int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
     int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
@@ -453,7 +454,7 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
 // First octave of the run that octave_tail_kernel takes (k_tail.hpp), or n_oct when it takes none: octaves >= 1 whose
 // planes are small enough to sit in LDS, all the way down to the last one.
 int tail_first_octave(const siftmi_plan *p) {
-    if (!p->opt.tail || p->profile || p->n_oct < 2) return p->n_oct;
+    if (!p->opt.tail || p->profile > 1 || p->n_oct < 2) return p->n_oct;   // full profile: every stage keeps its own launch and label
     for (int s = 0; s < 5; s++) {
         const int n = p->taps[s].n;
         if (n != 11 && n != 15 && n != 17 && n != 21 && n != 27) return p->n_oct;
@@ -711,6 +712,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "tile") o.tile = (int)v;
     else if (n == "ext_rows") o.ext_rows = (int)v;
     else if (n == "tail") o.tail = v != 0;
+    else if (n == "early_pyr") o.early_pyr = v != 0;
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
@@ -828,25 +830,16 @@ int enqueue_body(siftmi_plan *p) {
     const bool two = p->overlap && p->n_oct > 0;
     const bool chain0 = two && p->opt.chain0;
     const int tail_first = tail_first_octave(p);
-    for (int oct = 0; oct < p->n_oct; oct++) {
+    auto pyramid_stream = [&](int oct) { return (chain0 && oct > 0) ? p->stream3 : p->stream; };                                   // builds an octave's planes
+    auto detect_stream = [&](int oct) { return !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : p->stream3); };   // consumes them
+    bool built[SIFT_MAX_OCTAVES] = {false};
+    // shrink + five blurs of one octave on its pyramid stream (once)
+    auto build_pyramid = [&](int oct) -> int {
+        if (built[oct]) return SIFTMI_OK;
+        built[oct] = true;
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
-        hipStream_t pyr = (chain0 && oct > 0) ? p->stream3 : p->stream;                     // builds this octave's planes
-        hipStream_t dst = !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : p->stream3);   // consumes them
+        hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
         if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
-        if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp), then the group's descriptors
-            if (two) {
-                if (pyr != dst) {
-                    HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
-                    HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
-                }
-                if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
-            }
-            int rc = launch_tail(p, oct, dst);
-            if (rc) return rc;
-            launch_describe_group(p, 1, dst);
-            if (two) HIPCHK(hipEventRecord(p->ev_grp1, dst));
-            break;
-        }
         if (oct > 0) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
@@ -869,8 +862,32 @@ int enqueue_body(siftmi_plan *p) {
                 launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr);
             }
         }
+        if (two && (oct == 0 || pyr != dst)) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
+        return SIFTMI_OK;
+    };
+    for (int oct = 0; oct < p->n_oct; oct++) {
+        hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
+        if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp), then the group's descriptors
+            if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
+            if (two) {
+                if (pyr != dst) {
+                    HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
+                    HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
+                }
+                if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
+            }
+            int rc = launch_tail(p, oct, dst);
+            if (rc) return rc;
+            launch_describe_group(p, 1, dst);
+            if (two) HIPCHK(hipEventRecord(p->ev_grp1, dst));
+            break;
+        }
+        int rc = build_pyramid(oct);
+        if (rc) return rc;
+        // The chain of the later octaves is the long one on a small frame and the host feeds it last: put octave 1's
+        // pyramid in flight before octave 0's detection and description are enqueued (it needs only ev_pyr[0]).
+        if (oct == 0 && chain0 && p->opt.early_pyr && p->n_oct > 1 && tail_first != 1 && (rc = build_pyramid(1))) return rc;
         if (two) {
-            if (oct == 0 || pyr != dst) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
             if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
         }
@@ -1105,6 +1122,12 @@ int siftmi_batch_set_params(siftmi_batch *b, const siftmi_params *params) {
     return SIFTMI_OK;
 }
 
+int siftmi_batch_set_option(siftmi_batch *b, const char *name, int64_t value) {
+    if (!b) return fail(SIFTMI_EINVAL, "null batch");
+    for (siftmi_plan *p : b->lanes) { int rc = siftmi_plan_set_option(p, name, value); if (rc) return rc; }
+    return SIFTMI_OK;
+}
+
 int siftmi_batch_set_profile(siftmi_batch *b, int32_t level) {
     if (!b) return fail(SIFTMI_EINVAL, "null batch");
     if (level < 0 || level > 1) return fail(SIFTMI_EINVAL, "batch lanes support profile 0 or 1 (light)");
@@ -1224,13 +1247,22 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     if (images_are_device) HIPCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams
     const size_t L = b->lanes.size();
     int rc = SIFTMI_OK;
+    const bool htime = L > 0 && b->lanes[0]->opt.host_timing;   // diagnostic: where the host thread spends the batch
+    auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_retire = 0, t_enqueue = 0;
     for (int i = 0; i < n_images && !rc; i++) {
         if (!images[i]) { rc = fail(SIFTMI_EINVAL, "null image %d", i); break; }
         const size_t l = (size_t)i % L;
+        const double ta = htime ? tnow() : 0;
         if ((rc = batch_retire(b, l, overflow))) break;
-        if ((rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false))) break;
+        const double tb = htime ? tnow() : 0;
+        if (htime) b->lanes[l]->opt.host_timing = 0;             // the per-call line would flood
+        rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false);
+        if (htime) { b->lanes[l]->opt.host_timing = 1; t_retire += tb - ta; t_enqueue += tnow() - tb; }
+        if (rc) break;
         b->lane_image[l] = i;
     }
+    if (htime) fprintf(stderr, "[siftmi] batch of %d: waiting for lanes %.0f us, enqueueing %.0f us\n", n_images, t_retire, t_enqueue);
     for (int i = n_images > (int)L ? n_images - (int)L : 0; i < n_images && !rc; i++) rc = batch_retire(b, (size_t)i % L, overflow);
     b->host_outs = nullptr; b->host_caps = nullptr;
     if (rc) { std::string keep = g_err; batch_drain(b); g_err = keep; return rc; }

@@ -808,10 +808,30 @@ __global__ void blur_generic_pass(const float *__restrict__ in, float *__restric
 
 // ------------------------------------------------------------------------------------------
 // octave hand-off (shrink, preprocess.cl:267-285): next[y][x] = cur[2y][2x]
-__global__ void shrink_kernel(const float *__restrict__ in, float *__restrict__ out, int LW, int SW, int SH) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x < SW && y < SH) out[(size_t)y * SW + x] = in[(size_t)(2 * y) * LW + 2 * x];
+// A thread moves four consecutive outputs (two 16-byte loads, one 16-byte store where the pitches allow it) of two rows;
+// one output per thread made the 4096 -> 2048 hand-off a 16 k-workgroup launch that took 47-57 us for 84 MB of traffic.
+__global__ __launch_bounds__(256) void shrink_kernel(const float *__restrict__ in, float *__restrict__ out, int LW, int SW, int SH) {
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2;
+    if (x >= SW) return;
+    const bool vec_in = (LW & 1) == 0 && x + 3 < SW;     // row starts 2y * LW + 2x are then multiples of 4 floats
+    const bool vec_out = (SW & 3) == 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = y0 + r;
+        if (y >= SH) break;
+        const float *src = in + (size_t)(2 * y) * LW + 2 * x;
+        float *dst = out + (size_t)y * SW + x;
+        if (vec_in) {
+            const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+            if (vec_out) *reinterpret_cast<float4 *>(dst) = make_float4(a.x, a.z, b.x, b.z);
+            else { dst[0] = a.x; dst[1] = a.z; dst[2] = b.x; dst[3] = b.z; }
+        } else {
+            for (int k = 0; k < 4 && x + k < SW; k++) dst[k] = src[2 * k];
+        }
+    }
 }
+inline dim3 shrink_grid(int SW, int SH) { return dim3((unsigned)((SW + 255) / 256), (unsigned)((SH + 7) / 8)); }
 
 // normalise only (stage replay of preprocess.cl:239-252)
 template <int DT = 0>

@@ -101,6 +101,7 @@ struct Options {
     int desc_blocks = 2048, desc_pad = 0;    // descriptor launch: workgroups, bytes of dynamic LDS (residency throttle)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
+    int split_detect = 1;    // later octaves: detection on its own stream, off the chain of pyramids
     int early_pyr = 1;       // enqueue octave 1's pyramid before octave 0's detection / description
     int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
@@ -141,7 +142,7 @@ struct siftmi_plan {
     float *tmp = nullptr;         // generic blur only
     hipStream_t stream2 = nullptr;            // detection / description of octave 0 (overlaps the next octaves' pyramid)
     hipStream_t stream3 = nullptr;            // detection / description of the later octaves (overlaps group 0's descriptors)
-    hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr;
+    hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr, ev_det = nullptr;
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
@@ -611,7 +612,8 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
     if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&p->ev_grp1, hipEventDisableTiming) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
+                hipEventCreateWithFlags(&p->ev_grp1, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_det, hipEventDisableTiming) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
     p->overlap = true;
     for (int o = 0; o < p->n_oct && !rc; o++) {
         hipEvent_t e;
@@ -649,6 +651,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->stream3) { hipStreamSynchronize(p->stream3); hipStreamDestroy(p->stream3); }
     if (p->ev_mark0) hipEventDestroy(p->ev_mark0);
     if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
+    if (p->ev_det) hipEventDestroy(p->ev_det);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
     if (p->hb) hipHostFree(p->hb);
@@ -713,6 +716,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "ext_rows") o.ext_rows = (int)v;
     else if (n == "tail") o.tail = v != 0;
     else if (n == "early_pyr") o.early_pyr = v != 0;
+    else if (n == "split_detect") o.split_detect = v != 0;
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
@@ -831,7 +835,11 @@ int enqueue_body(siftmi_plan *p) {
     const bool chain0 = two && p->opt.chain0;
     const int tail_first = tail_first_octave(p);
     auto pyramid_stream = [&](int oct) { return (chain0 && oct > 0) ? p->stream3 : p->stream; };                                   // builds an octave's planes
-    auto detect_stream = [&](int oct) { return !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : p->stream3); };   // consumes them
+    // Later octaves: the pyramid of octave o+1 needs only plane 3 of octave o, not its detection.  With "split_detect" the
+    // extrema / refinement launches of octaves >= 1 go to `stream2` (idle in the chain0 layout), each behind the event
+    // of its pyramid, and the chain on `stream3` is pyramids only until the group's description, which waits for both.
+    const bool split = chain0 && p->opt.split_detect;
+    auto detect_stream = [&](int oct) { return !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : (split ? p->stream2 : p->stream3)); };   // consumes them
     bool built[SIFT_MAX_OCTAVES] = {false};
     // shrink + five blurs of one octave on its pyramid stream (once)
     auto build_pyramid = [&](int oct) -> int {
@@ -844,7 +852,7 @@ int enqueue_body(siftmi_plan *p) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
             Scope sc(p, lab, false, 0, pyr);
-            hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, pyr,
+            hipLaunchKernelGGL(shrink_kernel, shrink_grid(W, H), dim3(256), 0, pyr,
                                (const float *)p->plane(oct - 1, 3), p->plane(oct, 0), LW, W, H);
         }
         if (p->profile == 1) {
@@ -868,18 +876,23 @@ int enqueue_body(siftmi_plan *p) {
     for (int oct = 0; oct < p->n_oct; oct++) {
         hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
         if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp), then the group's descriptors
+            hipStream_t ts = two ? p->stream3 : p->stream;        // the tail builds pyramids too: it stays on the pyramid chain
             if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
             if (two) {
-                if (pyr != dst) {
+                if (pyr != ts) {
                     HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
-                    HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
+                    HIPCHK(hipStreamWaitEvent(ts, p->ev_pyr[(size_t)oct], 0));
                 }
-                if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
+                if (oct == 1 || split) HIPCHK(hipStreamWaitEvent(ts, p->ev_mark0, 0));
             }
-            int rc = launch_tail(p, oct, dst);
+            int rc = launch_tail(p, oct, ts);
             if (rc) return rc;
-            launch_describe_group(p, 1, dst);
-            if (two) HIPCHK(hipEventRecord(p->ev_grp1, dst));
+            if (split && oct > 1) {                               // detections of octaves 1 .. oct-1 on stream2
+                HIPCHK(hipEventRecord(p->ev_det, p->stream2));
+                HIPCHK(hipStreamWaitEvent(ts, p->ev_det, 0));
+            }
+            launch_describe_group(p, 1, ts);
+            if (two) HIPCHK(hipEventRecord(p->ev_grp1, ts));
             break;
         }
         int rc = build_pyramid(oct);
@@ -894,8 +907,13 @@ int enqueue_body(siftmi_plan *p) {
         launch_detect_octave(p, oct, dst);
         if (oct == 0) launch_describe_group(p, 0, dst);
         else if (oct == p->n_oct - 1) {
-            launch_describe_group(p, 1, dst);
-            if (two) HIPCHK(hipEventRecord(p->ev_grp1, dst));
+            hipStream_t ds = two ? p->stream3 : p->stream;        // group 1 is described (and the image ends) on stream3
+            if (dst != ds) {
+                HIPCHK(hipEventRecord(p->ev_det, dst));
+                HIPCHK(hipStreamWaitEvent(ds, p->ev_det, 0));
+            }
+            launch_describe_group(p, 1, ds);
+            if (two) HIPCHK(hipEventRecord(p->ev_grp1, ds));
         }
     }
     if (p->chain) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }   // no octave closed the light-profile bracket (n_oct == 0)
@@ -1885,7 +1903,7 @@ int siftmi_stage_shrink(int32_t dev, const float *in, float *out, int32_t W, int
     DevBuf a, o;
     if ((rc = a.upload(in, (size_t)W * H * 4)) || (rc = o.alloc((size_t)SW * SH * 4))) return rc;
     if (SW > 0 && SH > 0)
-        hipLaunchKernelGGL(shrink_kernel, dim3((unsigned)((SW + 255) / 256), (unsigned)SH), dim3(256), 0, 0, a.as<float>(), o.as<float>(), W, SW, SH);
+        hipLaunchKernelGGL(shrink_kernel, shrink_grid(SW, SH), dim3(256), 0, 0, a.as<float>(), o.as<float>(), W, SW, SH);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(out, o.p, (size_t)SW * SH * 4, hipMemcpyDeviceToHost));
     return SIFTMI_OK;

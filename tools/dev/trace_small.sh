@@ -8,7 +8,7 @@ import numpy as np, torch, time
 import sift_pyocl_amd as sp
 img = np.random.default_rng(0).random(($S, $S), dtype=np.float32)
 t = torch.from_numpy(img).cuda()
-plan = sp.SiftPlan(shape=img.shape, dtype=np.float32)
+plan = sp.SiftPlan(shape=img.shape, dtype=np.float32, octave_max=int("${2:-0}") or None)
 for _ in range(5): k = plan.keypoints(t)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): k = plan.keypoints(t)

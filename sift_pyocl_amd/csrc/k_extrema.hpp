@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "siftmath.hpp"
+#include <type_traits>
 
 namespace siftk {
 
@@ -53,9 +54,51 @@ __device__ __forceinline__ void ext_store_pending(const ExtWaveLdsT<BUF> &L, flo
     __builtin_amdgcn_wave_barrier();
 }
 
+// Edge test of the parked extrema [from, pending), compacted in place (image.cl:176-196).  The 2-D Hessian needs sixteen
+// more samples; taking them inside the row march made nearly every row of a textured frame run that divergent path for a
+// lane or two (white noise: 1.5 % of the samples are 27-neighbour extrema), so the march only parks the extrema and the
+// test runs here, one parked entry per lane.
+template <int BUF>
+__device__ __forceinline__ void ext_edge_filter(const BlurPlanes &b, int W, float edth, ExtWaveLdsT<BUF> &L, int from, int &pending, int lane) {
+    int out = from;
+    __builtin_amdgcn_wave_barrier();                                  // the entries were parked by other lanes of this wave
+    for (int base = from; base < pending; base += 64) {               // wave uniform
+        const int e = base + lane;
+        bool keep = false;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < pending) {
+            c = L.buf[e];
+            const float val = c.x;
+            const int s = (int)c.w;
+            const size_t pc = (size_t)(int)c.y * W + (int)c.z;
+            const float *pa = b.p[1], *pb = b.p[2];
+            if (s == 2) { pa = b.p[2]; pb = b.p[3]; } else if (s == 3) { pa = b.p[3]; pb = b.p[4]; }
+#define DOG_AT(o) (pa[pc + (o)] - pb[pc + (o)])
+            // 2-D Hessian; "2.0" and "4.0" are double literals in image.cl:180-184
+            const float up = DOG_AT(-(ptrdiff_t)W), dn = DOG_AT(W);
+            const float lf = DOG_AT(-1), rt = DOG_AT(1);
+            const float H00 = (float)(((double)up - 2.0 * (double)val) + (double)dn);
+            const float H11 = (float)(((double)lf - 2.0 * (double)val) + (double)rt);
+            const float dd = (DOG_AT(W + 1) - DOG_AT(W - 1)) - (DOG_AT(-(ptrdiff_t)W + 1) - DOG_AT(-(ptrdiff_t)W - 1));
+#undef DOG_AT
+            const float H01 = (float)((double)dd / 4.0);
+            const float det = H00 * H11 - H01 * H01;
+            const float tr = H00 + H11;
+            keep = !(det < edth * tr * tr) && val != 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();                              // every lane holds its entry before slots are rewritten
+        const unsigned long long m = __ballot(keep);
+        if (keep) L.buf[out + __popcll(m & ((1ull << lane) - 1ull))] = c;
+        out += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    pending = out;
+}
+
 // One wave marches strip (sx, sy) (all 64 lanes enter; an inactive wave does nothing but keeps the wave-wide operations
-// convergent).  Candidates are parked in L.buf; `pending` (wave uniform) counts them; a full buffer is flushed through
-// one atomicAdd.  What is still parked on return is the caller's to flush.
+// convergent).  Extrema are parked in L.buf; `pending` (wave uniform) counts them; a full buffer goes through the edge
+// test and is flushed through one atomicAdd.  What is still parked on return has passed the edge test and is the
+// caller's to flush.
 template <int BUF>
 __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H, int border, int rows, bool active, int sx, int sy,
                                               double contrast, float edth, float4 *__restrict__ cand, int *__restrict__ counter,
@@ -66,6 +109,20 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
     const bool col_ok = (lane >= 1) && (lane <= 62) && (x < W - border);
     const int ya = border + sy * rows;
     const int yb = active ? min(ya + rows, H - border) : ya - 2;
+    int tested = pending;                                // entries parked by earlier strips have had their edge test
+
+    // Row loop: loads address a plane as SGPR base + one 32-bit byte offset shared by the six planes, advanced by a row
+    // pitch per iteration (planes are < 4 GB); neighbour columns come through DPP wave shifts (lanes 0 / 63 receive 0:
+    // they are the halo columns, their results are never used); the contrast test (double)|v| > contrast (image.cl:152)
+    // is the float test |v| >= cf with cf the smallest float above `contrast` -- the same predicate without f64 work.
+    // (Measured on a 4096^2 plane: 0.098 ms whatever the instruction count -- 200 or 110 per row, ds_bpermute or DPP,
+    // 4 / 5 / 6 waves per SIMD, one or two rows of loads in flight, a hand-unrolled window without register moves was
+    // even slower: the launch moves 403 MB at 4.1 TB/s and that is its bound.)
+    float cf = (float)contrast;
+    if (!((double)cf > contrast)) cf = __uint_as_float(__float_as_uint(cf) + 1u);   // contrast >= 0: next float up
+    auto ld = [&](int k, unsigned off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(b.p[k]) + off); };
+    auto from_left = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); };    // wave_shr:1
+    auto from_right = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); };   // wave_shl:1
 
     float hM[3][3], hm[3][3];   // [row slot][scale]: horizontal+scale max / min for rows y-2, y-1, y
     float ctr[3] = {0.f, 0.f, 0.f}, ctr_next[3];
@@ -74,11 +131,12 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
 #pragma unroll
         for (int k = 0; k < 3; k++) { hM[r][k] = 0.f; hm[r][k] = 0.f; }
 
+    const unsigned pitch = (unsigned)W * 4u;
+    unsigned off = ((unsigned)max(ya - 1, 0) * (unsigned)W + (unsigned)xc) * 4u;   // byte offset of the row being loaded
     float vn[6];                                     // next row's samples, loaded one iteration ahead
     if (active) {
-        const size_t pos0 = (size_t)(ya - 1) * W + xc;
 #pragma unroll
-        for (int k = 0; k < 6; k++) vn[k] = b.p[k][pos0];
+        for (int k = 0; k < 6; k++) vn[k] = ld(k, off);
     } else {
 #pragma unroll
         for (int k = 0; k < 6; k++) vn[k] = 0.f;
@@ -88,9 +146,9 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
 #pragma unroll
         for (int k = 0; k < 6; k++) v[k] = vn[k];
         if (y < yb) {
-            const size_t posn = (size_t)(y + 1) * W + xc;
+            off += pitch;
 #pragma unroll
-            for (int k = 0; k < 6; k++) vn[k] = b.p[k][posn];
+            for (int k = 0; k < 6; k++) vn[k] = ld(k, off);
         }
         float d[5];
 #pragma unroll
@@ -102,10 +160,8 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
         for (int k = 0; k < 3; k++) {
             const float M = fmaxf(fmaxf(d[k], d[k + 1]), d[k + 2]);
             const float m = fminf(fminf(d[k], d[k + 1]), d[k + 2]);
-            const float Ml = __shfl_up(M, 1), Mr = __shfl_down(M, 1);
-            const float ml = __shfl_up(m, 1), mr = __shfl_down(m, 1);
-            hM[2][k] = fmaxf(fmaxf(Ml, M), Mr);
-            hm[2][k] = fminf(fminf(ml, m), mr);
+            hM[2][k] = fmaxf(fmaxf(from_left(M), M), from_right(M));
+            hm[2][k] = fminf(fminf(from_left(m), m), from_right(m));
             ctr_next[k] = d[k + 1];
         }
         // centre row is y-1; it is complete once rows y-2, y-1, y have been seen
@@ -115,25 +171,10 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float val = ctr[k];
-                if ((double)fabsf(val) > contrast) {
+                if (fabsf(val) >= cf) {
                     const float M27 = fmaxf(fmaxf(hM[0][k], hM[1][k]), hM[2][k]);
                     const float m27 = fminf(fminf(hm[0][k], hm[1][k]), hm[2][k]);
-                    const bool is_ext = (val > 0.0f) ? (val >= M27) : (val <= m27);
-                    if (is_ext) {
-                        const int s = k + 1;
-                        const size_t pc = (size_t)yc * W + x;
-                        // 2-D Hessian; "2.0" and "4.0" are double literals in image.cl:180-184
-                        const float up = dog_at(b, s, pc - W), dn = dog_at(b, s, pc + W);
-                        const float lf = dog_at(b, s, pc - 1), rt = dog_at(b, s, pc + 1);
-                        const float H00 = (float)(((double)up - 2.0 * (double)val) + (double)dn);
-                        const float H11 = (float)(((double)lf - 2.0 * (double)val) + (double)rt);
-                        const float dd = (dog_at(b, s, pc + W + 1) - dog_at(b, s, pc + W - 1)) -
-                                         (dog_at(b, s, pc - W + 1) - dog_at(b, s, pc - W - 1));
-                        const float H01 = (float)((double)dd / 4.0);
-                        const float det = H00 * H11 - H01 * H01;
-                        const float tr = H00 + H11;
-                        found[k] = !(det < edth * tr * tr) && val != 0.0f;
-                    }
+                    found[k] = (val > 0.0f) ? (val >= M27) : (val <= m27);
                 }
             }
         }
@@ -146,7 +187,9 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
                 pending += __popcll(m);
             }
         }
-        if (pending > BUF) {                                 // wave uniform: reserve slots for the whole buffer
+        if (pending > BUF) {                                 // wave uniform: edge test, then slots for the whole buffer
+            ext_edge_filter(b, W, edth, L, tested, pending, lane);
+            tested = 0;
             int slot = 0;
             if (lane == 0) slot = atomicAdd(counter, pending);
             ext_store_pending(L, cand, capacity, __shfl(slot, 0), pending, lane);
@@ -155,6 +198,7 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
 #pragma unroll
         for (int k = 0; k < 3; k++) ctr[k] = ctr_next[k];
     }
+    ext_edge_filter(b, W, edth, L, tested, pending, lane);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,

@@ -19,7 +19,7 @@ namespace siftk {
 
 #define SIFT_TAIL_MAX_OCT 6          // octaves one launch can walk
 #define SIFT_TAIL_MAX_PIXELS 4096    // largest plane (W * H) taken; both sides also <= 128 and >= 14 (reflection stays in range)
-#define SIFT_TAIL_THREADS 512
+#define SIFT_TAIL_THREADS 512      // measured on a 512^2 frame (64^2 + 32^2 + 16^2 octaves): 512 threads 55 us, 1024 (128 VGPRs, spills) 62 us, 256 64 us
 #define SIFT_TAIL_EXT_BUF 32
 
 struct TailOctave {

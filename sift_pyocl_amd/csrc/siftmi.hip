@@ -101,8 +101,8 @@ struct Options {
     int desc_blocks = 2048, desc_pad = 0;    // descriptor launch: workgroups, bytes of dynamic LDS (residency throttle)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
-    int split_detect = 1;    // later octaves: detection on its own stream, off the chain of pyramids
-    int early_pyr = 1;       // enqueue octave 1's pyramid before octave 0's detection / description
+    int split_detect = 0;    // later octaves: detection on its own stream, off the chain of pyramids (interleaved A/B: 512^2 -3 %, 2048^2 / 4096^2 +-1 %, two pipelined 4096^2 lanes +10 %: off)
+    int early_pyr = 0;       // enqueue octave 1's pyramid before octave 0's detection / description (A/B: no gain anywhere, 512^2 +2 %)
     int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
     int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
@@ -897,8 +897,8 @@ int enqueue_body(siftmi_plan *p) {
         }
         int rc = build_pyramid(oct);
         if (rc) return rc;
-        // The chain of the later octaves is the long one on a small frame and the host feeds it last: put octave 1's
-        // pyramid in flight before octave 0's detection and description are enqueued (it needs only ev_pyr[0]).
+        // Option "early_pyr": octave 1's pyramid is enqueued before octave 0's detection and description (it needs only
+        // ev_pyr[0]).  Off by default: the host is not what delays that chain.
         if (oct == 0 && chain0 && p->opt.early_pyr && p->n_oct > 1 && tail_first != 1 && (rc = build_pyramid(1))) return rc;
         if (two) {
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));

@@ -16,6 +16,9 @@ bash tools/dev/trace_gaps.sh > $OUT/timeline_white4096.txt 2>&1
 for k in descriptor_kernel orientation_kernel extrema_kernel; do bash tools/dev/pmc_kernel.sh $k > $OUT/pmc_$k.txt 2>&1; done
 python tools/bench_match.py > $OUT/match_100k.txt 2>&1
 python tools/dev/quick_smooth.py > $OUT/configs.txt 2>&1
+python tools/dev/small_frames.py tail 1 0 sizes=256,512,1024,2048 > $OUT/small_frames.txt 2>&1
+python tools/dev/small_frames.py tail 1 sizes=512,1024,2048 kind=smooth >> $OUT/small_frames.txt 2>&1
+bash tools/dev/trace_small.sh 512 > $OUT/timeline_white512.txt 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --config c4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2>> $OUT/bench.err
 ls -la $OUT

@@ -7,10 +7,10 @@ import sift_pyocl_amd as sp
 name = sys.argv[1]
 vals = [int(v) for v in sys.argv[2:] if v.lstrip("-").isdigit()]
 kw = dict(a.split("=") for a in sys.argv[2:] if "=" in a)
-size = int(kw.get("size", 2048)); lanes = int(kw.get("lanes", 8)); n = int(kw.get("n", 64))
+size = int(kw.get("size", 2048)); lanes = int(kw.get("lanes", 8)); n = int(kw.get("n", 64)); octaves = int(kw.get("octaves", 0))
 imgs = [torch.from_numpy(np.random.default_rng(i).random((size, size), dtype=np.float32)).cuda() for i in range(n)]
 for v in vals:
-    bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, lanes=lanes)
+    bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, lanes=lanes, octave_max=octaves or None)
     bp.set_option(name, v)
     for _ in range(2): bp.keypoints_batch_device(imgs)
     torch.cuda.synchronize(); t0 = time.perf_counter()

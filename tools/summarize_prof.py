@@ -45,12 +45,14 @@ for r in trace:
 print("\n== kernel trace by (kernel, grid threads): calls, avg_us, min_us")
 b0_t = b0_n = 0
 bigg = {}
+# full resolution = the marching instances on their largest grid (the tile kernel only ever sees small octaves)
+is_full = lambda n: n.startswith("blur_team") or n.startswith("blur_march")
 for (n, g) in per:
-    if n.startswith("blur_"):
+    if is_full(n):
         bigg[n] = max(bigg.get(n, 0), g)
 for (n, g), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     print("%-40s %10d %6d %10.2f %10.2f" % (n[:40], g, len(v), sum(v) / len(v), min(v)))
-    if n.startswith("blur_") and g == bigg[n]:
+    if is_full(n) and g == bigg[n]:
         b0_t += sum(v); b0_n += len(v)
 if b0_n:
     print("full-resolution blur launches: %d calls, avg %.2f us" % (b0_n, b0_t / b0_n))
@@ -82,12 +84,11 @@ for k in keys[:40]:
 # 16-byte loads read exactly 4 B/pixel and are reported at 1/2), writes x1 (blur / shrink stores are exact)
 import json
 cal = [v for (n, g), vs in fetch.items() if n == "minmax_kernel" for v in vs]
-# full-resolution launches only (the largest grid of each blur instance), as bench.py's roofline object
-big = {}
-for (n, g) in list(fetch) + list(write):
-    if n.startswith("blur_"):
-        big[n] = max(big.get(n, 0), int(g))
-sel = lambda n, g: n.startswith("blur_") and int(g) == big[n]
+# full-resolution launches only (the blur launches that write a whole octave-0 plane), as bench.py's roofline object
+avg_w = {k: sum(v) / len(v) for k, v in write.items() if k[0].startswith("blur_") and v}
+full = max(avg_w.values()) if avg_w else 0.0
+full_keys = {k for k, w in avg_w.items() if w >= 0.99 * full}
+sel = lambda n, g: (n, g) in full_keys
 nb = sum(len(v) for (n, g), v in fetch.items() if sel(n, g))
 fb = sum(sum(v) for (n, g), v in fetch.items() if sel(n, g)) * 1024.0
 wb = sum(sum(v) for (n, g), v in write.items() if sel(n, g)) * 1024.0

@@ -110,16 +110,11 @@ __device__ __forceinline__ void descriptor_sample(const float *__restrict__ I, i
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
-void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
-                       int group, int range_start, int range_end,   // range used when cnt == nullptr
-                       int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity) {
-    __shared__ DescRowLds lds_all[4];
-    __shared__ double fold[36];
+__device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
+                                                 int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
+                                                 int host_capacity, DescRowLds *lds_all, double *fold) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
-    int start = range_start, end = range_end;
-    if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
     siftmath::load_atan_fold(fold);
     L.mask[lane] = make_uint2(0u, 0u); L.mask[lane + 64] = make_uint2(0u, 0u);
     if (lane < 4) L.pool[896 + lane] = 0.0f;
@@ -329,6 +324,262 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
         store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.V));
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same descriptor, ONE WORKGROUP (four waves) per keypoint: for sparse groups.  With a wave per keypoint a launch
+// lasts as long as its slowest keypoint (60-120 us: ~40-75 batches of 64 samples, one after the other, on a SIMD that
+// has nothing else to issue), however few keypoints there are.  Here the four waves evaluate four consecutive batches
+// at once, each into its own mask / pool area, and after a workgroup barrier the bin owners (threads 0-127, one bin
+// each) add the four areas in batch order -- the same additions in the same order, so the same bits.  One launch holds
+// both forms; the group's count, known on the device only, picks one (descriptor_kernel, team_below).
+struct alignas(16) DescTeamWaveLds {
+    float pool[1024];                          // as DescRowLds::pool
+    uint2 mask[128];
+    unsigned mbase[128];
+};
+struct alignas(16) DescTeamLds {
+    DescTeamWaveLds w[4];
+    float V[128];
+    int Q[128];
+    int row_start[2 * SIFT_DESC_MAXRAD + 4];
+    short row_jlo[2 * SIFT_DESC_MAXRAD + 4];
+    int blk_total[4];
+};
+
+__device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
+                                                int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
+                                                int host_capacity, DescTeamLds &T, double *fold) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    DescTeamWaveLds &L = T.w[wave];
+    siftmath::load_atan_fold(fold);
+    L.mask[lane] = make_uint2(0u, 0u); L.mask[lane + 64] = make_uint2(0u, 0u);
+    if (lane < 4) L.pool[896 + lane] = 0.0f;
+    __syncthreads();
+
+    for (int i = start + blockIdx.x; i < end; i += gridDim.x) {      // workgroup uniform
+        const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
+        const int aux = oaux[i];         // detection scale | octave << 8
+        const int scale = aux & 0xff, oct = aux >> 8;
+        const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
+        KpRecord *rec = records + i;
+        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
+        if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
+            __syncthreads();             // the previous keypoint's record may still be leaving through T.V
+            if (wave == 0) store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(T.V));
+            continue;
+        }
+        const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
+        const float foct = (float)octsize;
+        const float row = kq.y / foct, col = kq.x / foct, angle = kq.w;
+        const int irow = (int)(row + 0.5f), icol = (int)(col + 0.5f);
+        float sine, cosine;
+        siftmath::sincosf_(angle, &sine, &cosine);
+        const float spacing = kq.z / foct * 3.0f;
+        const int R = (int)((1.414f * spacing * 2.5f) + 0.5f);
+        const float drow = row - (float)irow, dcol = col - (float)icol;
+        const int S = 2 * R + 1;
+        if (R > SIFT_DESC_MAXRAD) __builtin_trap();   // the host launches descriptor_stream_kernel for such plans
+
+        // ---- 1a. thresholds (every wave for itself: 64 candidates in one ballot), as in descriptor_kernel
+        auto g = [&](float u) { return u / spacing + 1.5f; };
+        float t_hi = 0.0f, t_lo = 0.0f;
+        bool thr_ok = spacing > 1e-30f && spacing < 1e30f;
+        if (thr_ok) {
+            const float cand = __int_as_float(__float_as_int(2.5f * spacing) + lane - 32);
+            const unsigned long long m_hi = __ballot(g(cand) >= 4.0f), m_lo = __ballot(g(-cand) <= -1.0f);
+            const int i_hi = m_hi ? __ffsll(m_hi) - 1 : 0, i_lo = m_lo ? __ffsll(m_lo) - 1 : 0;
+            thr_ok = i_hi > 0 && i_lo > 0 && (m_hi >> i_hi) == (~0ull >> i_hi) && (m_lo >> i_lo) == (~0ull >> i_lo);
+            t_hi = __shfl(cand, i_hi);
+            t_lo = -__shfl(cand, i_lo);
+        }
+        auto below_hi = [&](float u) { return thr_ok ? (u < t_hi) : (g(u) < 4.0f); };
+        auto above_lo = [&](float u) { return thr_ok ? (u > t_lo) : (g(u) > -1.0f); };
+
+        // ---- 1b. row intervals: thread t owns window row t (S <= 255)
+        {
+            const bool rdec = sine >= 0.0f, cdec = !(cosine >= 0.0f);
+            const int iters = 32 - __clz(S);
+            const int r = tid;
+            const int ii = r - R;
+            const float fi = (float)ii;
+            const float ci_ = cosine * fi, si_ = sine * fi;
+            int lo[4], hi[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { lo[q] = -R; hi[q] = R + 1; }
+            if (64 * wave < S) {                                      // wave uniform
+#pragma unroll 1
+                for (int it = 0; it < iters; it++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int mid = (lo[q] + hi[q]) >> 1;
+                        const float fj = (float)mid;
+                        const float u = (q < 2) ? ((ci_ - sine * fj) - drow) : ((si_ + cosine * fj) - dcol);
+                        const bool dec = (q < 2) ? rdec : cdec;
+                        bool pred;
+                        if ((q & 1) == 0) pred = dec ? below_hi(u) : above_lo(u);
+                        else pred = dec ? !above_lo(u) : !below_hi(u);
+                        if (lo[q] < hi[q]) { if (pred) hi[q] = mid; else lo[q] = mid + 1; }
+                    }
+                }
+            }
+            const int jlo = max(max(lo[0], lo[2]), max(-R, -icol));
+            const int jhi = min(min(lo[1], lo[3]) - 1, min(R, W - 1 - icol));
+            const int yy = irow + ii;
+            int c = jhi - jlo + 1;
+            if (r >= S || yy < 0 || yy >= H || c < 0) c = 0;
+            const int incl = wave_prefix_incl(c);
+            if (lane == 63) T.blk_total[wave] = incl;
+            __syncthreads();                                          // (also: the previous keypoint's epilogue is over)
+            int offset = 0;
+            for (int q = 0; q < wave; q++) offset += T.blk_total[q];
+            if (r < S) { T.row_start[r] = offset + incl - c; T.row_jlo[r] = (short)jlo; }
+            if (tid == 0) T.row_start[S] = T.blk_total[0] + T.blk_total[1] + T.blk_total[2] + T.blk_total[3];
+            __syncthreads();
+        }
+        const int total = T.row_start[S];
+
+        // ---- 2 + 3. four batches of 64 ranks at a time, one per wave
+        const float rspacing = 1.0f / spacing;
+        const bool fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;
+        const bool interior = irow - R >= 1 && irow + R <= H - 2 && icol - R >= 1 && icol + R <= W - 2;
+        float4 *pool4 = reinterpret_cast<float4 *>(L.pool);
+        float acc = 0.0f;                // bin tid (threads 0-127)
+        int rcur = 0;
+        for (int t0 = 0; t0 < total; t0 += 256) {                     // workgroup uniform
+            const int s = t0 + 64 * wave + lane;
+            if (t0 + 64 * wave < total) {                             // wave uniform: this wave has a batch
+                int cbin[8];
+                float cval[8];
+#pragma unroll
+                for (int n8 = 0; n8 < 8; n8++) { cbin[n8] = -1; cval[n8] = 0.0f; }
+                if (s < total) {
+                    while (s >= T.row_start[rcur + 1]) rcur++;
+                    const int ii = rcur - R, jj = (int)T.row_jlo[rcur] + (s - T.row_start[rcur]);
+                    const float ur = (cosine * (float)ii - sine * (float)jj) - drow, uc = (sine * (float)ii + cosine * (float)jj) - dcol;
+                    const float rx = (fast_div ? siftmath::div_by_reciprocal(ur, spacing, rspacing) : ur / spacing) + 1.5f;
+                    const float cx = (fast_div ? siftmath::div_by_reciprocal(uc, spacing, rspacing) : uc / spacing) + 1.5f;
+                    if (interior) descriptor_sample<true>(I, W, H, icol + jj, irow + ii, rx, cx, angle, fold, cbin, cval);
+                    else descriptor_sample<false>(I, W, H, icol + jj, irow + ii, rx, cx, angle, fold, cbin, cval);
+                }
+                // 3a. contributor masks of this wave's batch
+                {
+                    const unsigned bit = 1u << (lane & 31);
+                    unsigned *mw = reinterpret_cast<unsigned *>(L.mask) + (lane >> 5);
+#pragma unroll
+                    for (int n8 = 0; n8 < 8; n8++)
+                        if (cbin[n8] >= 0) atomicOr(mw + 2 * cbin[n8], bit);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // 3b. segments of this wave's pool
+                const uint2 ia = L.mask[lane], ib = L.mask[lane + 64];
+                const int cnta = __popc(ia.x) + __popc(ia.y), cntb = __popc(ib.x) + __popc(ib.y);
+                const int pa = (cnta + 3) & ~3, pb = (cntb + 3) & ~3;
+                const int base_a = wave_prefix_incl(pa + pb) - (pa + pb);
+                const int base_b = base_a + pa;
+                L.mbase[lane] = (unsigned)base_a;
+                L.mbase[lane + 64] = (unsigned)base_b;
+                if (cnta) pool4[(base_a + pa - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cntb) pool4[(base_b + pb - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                __builtin_amdgcn_wave_barrier();
+                // 3c. values to their ranks (branch free, see descriptor_kernel)
+                uint2 mk[8];
+                unsigned mb[8];
+#pragma unroll
+                for (int n8 = 0; n8 < 8; n8++) {
+                    const int b = max(cbin[n8], 0);
+                    mk[n8] = L.mask[b];
+                    mb[n8] = L.mbase[b];
+                }
+#pragma unroll
+                for (int n8 = 0; n8 < 8; n8++) {
+                    const int pos = mb[n8] + __builtin_amdgcn_mbcnt_hi(mk[n8].y, __builtin_amdgcn_mbcnt_lo(mk[n8].x, 0u));
+                    L.pool[(cbin[n8] >= 0) ? pos : 960 + lane] = cval[n8];
+                }
+            }
+            __syncthreads();
+            // 3d. owners: bin tid, the four areas in batch order (an area without a batch this round has empty masks)
+            if (tid < 128) {
+                uint2 m[4];
+                unsigned mb[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { m[q] = T.w[q].mask[tid]; mb[q] = T.w[q].mbase[tid]; }
+                int n4[4];
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    n4[q] = (__popc(m[q].x) + __popc(m[q].y) + 3) >> 2;
+                    v[q] = reinterpret_cast<const float4 *>(T.w[q].pool)[n4[q] ? (mb[q] >> 2) : 224];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (n4[q]) {
+                        float4 cur = v[q];
+                        for (int g4 = 0; g4 < n4[q]; g4++) {
+                            const float4 c4 = cur;
+                            if (g4 + 1 < n4[q]) cur = reinterpret_cast<const float4 *>(T.w[q].pool)[(mb[q] >> 2) + g4 + 1];
+                            acc = acc + c4.x; acc = acc + c4.y; acc = acc + c4.z; acc = acc + c4.w;
+                        }
+                        T.w[q].mask[tid] = make_uint2(0u, 0u);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- 4. normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160), as in descriptor_kernel
+        auto sum_squares = [&]() {
+            float t = 0.0f;
+#pragma unroll 1
+            for (int k8 = 0; k8 < 4; k8++) {
+                float4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) q[u] = reinterpret_cast<const float4 *>(T.V)[8 * k8 + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { t = t + q[u].x; t = t + q[u].y; t = t + q[u].z; t = t + q[u].w; }
+            }
+            return t;
+        };
+        if (tid < 128) T.V[tid] = acc * acc;
+        __syncthreads();
+        const float norm = 1.0f / sqrtf(sum_squares());
+        acc = acc * norm;
+        const bool ch = tid < 128 && acc > 0.2f;
+        if (acc > 0.2f) acc = 0.2f;
+        if (__syncthreads_or(ch)) {                                   // (a barrier: every thread has read T.V)
+            if (tid < 128) T.V[tid] = acc * acc;
+            __syncthreads();
+            const float n2 = 1.0f / sqrtf(sum_squares());
+            acc = acc * n2;
+        }
+        // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see the oracle's note)
+        if (tid < 128) T.Q[tid] = min(255, (acc == acc) ? (int)(512.0 * (double)acc) : 0);
+        __syncthreads();                                              // T.Q complete, T.V free
+        if (wave == 0) store_record(rec, hrec, kq, T.Q[lane], T.Q[lane + 64], lane, reinterpret_cast<unsigned char *>(T.V));
+        // the next keypoint's first barrier (1b) orders this store_record before anything rewrites T.V / T.Q
+    }
+}
+
+// The launch: both forms share the grid (workgroups of four waves), the LDS block and the fold table; the count of the
+// group decides -- fewer than `team_below` oriented keypoints: a workgroup per keypoint, else a wave per keypoint.
+// Measured cross-over 1000-1800 keypoints (a 256-CU device holds 1024 workgroups of this kernel at once).
+union DescLds {
+    DescRowLds rows[4];
+    DescTeamLds team;
+    __device__ DescLds() {}
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
+void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
+                       int group, int range_start, int range_end,   // range used when cnt == nullptr
+                       int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
+                       int team_below) {
+    __shared__ DescLds lds;
+    __shared__ double fold[36];
+    int start = range_start, end = range_end;
+    if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
+    if (end - start < team_below) descriptor_team(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.team, fold);
+    else descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold);
 }
 
 }  // namespace siftk

@@ -66,6 +66,12 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
     plan.set_option("desc_stream", 1)
     assert_same_keypoints(plan.keypoints(img), want, "streaming form")
     plan.set_option("desc_stream", 0)
+    # one launch holds a wave-per-keypoint and a workgroup-per-keypoint form; the group's count picks one ("desc_team")
+    plan.set_option("desc_team", 1 << 30)
+    assert_same_keypoints(plan.keypoints(img), want, "workgroup-per-keypoint form for every group")
+    plan.set_option("desc_team", 0)
+    assert_same_keypoints(plan.keypoints(img), want, "wave-per-keypoint form for every group")
+    plan.set_option("desc_team", 1024)
     plan.pinned_results = False                                  # plain numpy result + device-to-host copy
     assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
     for init_sigma in (3.0, 4.0):
@@ -75,6 +81,9 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
         assert_same_keypoints(got, oracle.keypoints(img, par=oracle.default_params(init_sigma=init_sigma)), "init_sigma %g" % init_sigma)
         big.set_option("desc_stream", 1)
         assert_same_keypoints(big.keypoints(img), got, "init_sigma %g, streaming form" % init_sigma)
+        big.set_option("desc_stream", 0)
+        big.set_option("desc_team", 1 << 30)
+        assert_same_keypoints(big.keypoints(img), got, "init_sigma %g, workgroup-per-keypoint form" % init_sigma)
 
 
 def test_result_arrays_outlive_the_plan_and_recycle(siftlib):
@@ -109,7 +118,8 @@ def test_small_frame_kernels_agree(siftlib, oracle, shape):
     assert len(base) > 5
     if want is not None:
         assert_same_keypoints(base, want, "defaults vs oracle %r" % (shape,))
-    for opts in (dict(tail=0), dict(tail=0, tile=1, ext_rows=32), dict(tail=1, tile=2, ext_rows=8), dict(tail=1, overlap=0)):
+    for opts in (dict(tail=0), dict(tail=0, tile=1, ext_rows=32), dict(tail=1, tile=2, ext_rows=8), dict(tail=1, overlap=0),
+                 dict(split_detect=1, early_pyr=1), dict(desc_team=0), dict(desc_team=1 << 30, chain0=0)):
         other = sp.SiftPlan(template=img)
         for name, value in opts.items():
             other.set_option(name, value)

@@ -110,9 +110,12 @@ __device__ __forceinline__ void descriptor_sample(const float *__restrict__ I, i
     }
 }
 
+// `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
+// after that it asks the counter, so that a wave with a small window does not idle while another still has two large
+// ones to go (windows differ by 4x in samples within an octave).
 __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
                                                  int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
-                                                 int host_capacity, DescRowLds *lds_all, double *fold) {
+                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
     siftmath::load_atan_fold(fold);
@@ -121,7 +124,13 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
     __syncthreads();                     // the only workgroup barrier: the fold table
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
 
-    for (int i = start + gwave; i < end; i += nwaves) {
+    auto advance = [&](int i) {
+        if (!next) return i + nwaves;
+        int t = 0;
+        if (lane == 0) t = atomicAdd(next, 1);
+        return start + nwaves + __builtin_amdgcn_readfirstlane(t);
+    };
+    for (int i = start + gwave; i < end; i = advance(i)) {
         const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
         const int aux = oaux[i];         // detection scale | octave << 8
         const int scale = aux & 0xff, oct = aux >> 8;
@@ -573,13 +582,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_W
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
                        int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
-                       int team_below) {
+                       int team_below, int dynamic) {
     __shared__ DescLds lds;
     __shared__ double fold[36];
     int start = range_start, end = range_end;
     if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
     if (end - start < team_below) descriptor_team(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.team, fold);
-    else descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold);
+    else descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
+                          (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr);
 }
 
 }  // namespace siftk

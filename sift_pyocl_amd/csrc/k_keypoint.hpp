@@ -77,6 +77,7 @@ struct Counters {
     int n_cand[SIFT_MAX_OCTAVES];       // candidates per octave
     uint32_t mm[2];                     // order-encoded min / max of the input (k_pyramid.hpp), read back with the counters
     int tail_ready[8];                  // octave_tail_kernel: plane 3 of tail octave k is in HBM (k_tail.hpp)
+    int desc_next[SIFT_GROUPS + 1];     // descriptor_kernel: keypoints of the group handed out beyond every wave's first one
 };
 
 // where the six planes of every octave live: plane(o, s) = base + off[o] + s * W[o] * H[o]
@@ -98,7 +99,7 @@ __global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_c
 __global__ void begin_image_kernel(Counters *c) {
     const int t = threadIdx.x;
     if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; c->mm[0] = 0xffffffffu; c->mm[1] = 0u; }
-    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; }
+    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; c->desc_next[t] = 0; }
     if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
     if (t < 8) c->tail_ready[t] = 0;
 }

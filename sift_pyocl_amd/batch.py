@@ -24,7 +24,7 @@ class BatchPlan(SiftPlan):
 
     ``lanes`` independent device plans take the frames round-robin; nothing waits on the host until a lane is
     reused, the records of the whole batch are parked on the device and come back in one copy
-    (``siftmi_batch_*`` in include/siftmi.h).  Same constructor keywords as ``SiftPlan`` plus ``lanes`` (default: 8 for frames up to 2048 x 2048, else 2);
+    (``siftmi_batch_*`` in include/siftmi.h).  Same constructor keywords as ``SiftPlan`` plus ``lanes`` (default: 16 for frames up to 2048 x 2048, 8 below 600 x 600, 2 for larger ones);
     ``keypoints_batch(images)`` returns one recarray per frame, each bit-identical to ``SiftPlan.keypoints``.
     """
 
@@ -34,7 +34,10 @@ class BatchPlan(SiftPlan):
             # measured on MI355X: many one-stream lanes for small frames (dependent-launch latency), two three-stream lanes
             # for large ones (one frame nearly fills the GPU)
             shape = kwargs.get("shape") or (kwargs["template"].shape if kwargs.get("template") is not None else (args[0] if args else None))
-            lanes = 8 if shape is not None and int(shape[0]) * int(shape[1]) <= 2048 * 2048 else 2
+            # (64 frames, ms per batch, 8 / 16 / 32 lanes: 2048^2 21.6 / 20.0 / 18.9, 1024^2 14.7 / 12.9, 512^2 10.2 / 11.1 --
+            # the host thread needs ~0.12 ms to enqueue a frame, which is what bounds the smallest frames)
+            px = int(shape[0]) * int(shape[1]) if shape is not None else 0
+            lanes = 2 if px == 0 or px > 2048 * 2048 else (16 if px > 600 * 600 else 8)
         self.lanes = int(lanes)
         self._records_per_frame = 4096.0
         self._light = kwargs.get("profile") == "light"

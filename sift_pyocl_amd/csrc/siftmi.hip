@@ -97,7 +97,7 @@ struct Options {
     int march_nt = 128;      // threads per workgroup of the one-block form (64 or 128)
     int march_wgs = 0;       // workgroups wanted by the marching blur (0: 1024, 768 for 27 taps)
     int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
-    int ori_blocks = 1024, ori_pad = 0;
+    int ori_blocks = 4096, ori_pad = 0;      // orientation launch: workgroups (upper bound; the kernel cuts it down by the group's count)
     int desc_blocks = 1024, desc_pad = 0;    // descriptor launch: workgroups (1024 = one resident set at 4 per CU; keypoints are handed out dynamically), bytes of dynamic LDS (residency throttle)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line

@@ -115,14 +115,14 @@ __device__ __forceinline__ void descriptor_sample(const float *__restrict__ I, i
 // ones to go (windows differ by 4x in samples within an octave).
 __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
                                                  int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
-                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next) {
+                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
     siftmath::load_atan_fold(fold);
     L.mask[lane] = make_uint2(0u, 0u); L.mask[lane + 64] = make_uint2(0u, 0u);
     if (lane < 4) L.pool[896 + lane] = 0.0f;
     __syncthreads();                     // the only workgroup barrier: the fold table
-    const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
 
     auto advance = [&](int i) {
         if (!next) return i + nwaves;
@@ -582,14 +582,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_W
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
                        int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
-                       int team_below, int dynamic) {
+                       int team_below, int dynamic, int dense_blocks) {
     __shared__ DescLds lds;
     __shared__ double fold[36];
     int start = range_start, end = range_end;
     if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
     if (end - start < team_below) descriptor_team(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.team, fold);
-    else descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
-                          (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr);
+    else {
+        // three workgroups per CU instead of four on a dense group: 154 k keypoints 5.56 -> 5.45 ms per call (the 9 k
+        // keypoints of the headline frame prefer the full set: 0.903 against 0.927 ms)
+        const int nblocks = (end - start >= 65536) ? min((int)gridDim.x, dense_blocks) : (int)gridDim.x;
+        if ((int)blockIdx.x >= nblocks) return;
+        descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
+                         (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr, nblocks);
+    }
 }
 
 }  // namespace siftk

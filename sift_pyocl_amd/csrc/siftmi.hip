@@ -98,7 +98,11 @@ struct Options {
     int march_wgs = 0;       // workgroups wanted by the marching blur (0: 1024, 768 for 27 taps)
     int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
     int ori_blocks = 4096, ori_pad = 0;      // orientation launch: workgroups (upper bound; the kernel cuts it down by the group's count)
-    int desc_blocks = 1024, desc_pad = 0;    // descriptor launch: workgroups (1024 = one resident set at 4 per CU; keypoints are handed out dynamically), bytes of dynamic LDS (residency throttle)
+    // descriptor launch: workgroups (keypoints are handed out dynamically, so a workgroup stays until the group is done:
+    // 1024 = every wave slot of the chip, which starves the other stream's kernels for the whole launch -- 1024^2 smooth
+    // frame 0.760 ms, with 896-960 workgroups 0.671; 2048^2 smooth 1.85 -> 1.73), bytes of dynamic LDS (residency throttle)
+    int desc_blocks = 960, desc_pad = 0;
+    int desc_dense_blocks = 832;   // ... and for groups of >= 65536 keypoints (704: 5.47 ms per 154 k-keypoint call, 768-896: 5.27, 960: 5.31)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
@@ -527,7 +531,7 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
             // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
             // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
             hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic);
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks);
         } else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                                (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
@@ -723,6 +727,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "split_detect") o.split_detect = v != 0;
     else if (n == "desc_team") o.desc_team = v > 0 ? v : 0;
     else if (n == "desc_dynamic") o.desc_dynamic = v != 0;
+    else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
@@ -1890,7 +1895,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
         if (block_ok)
             hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0);
+                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,

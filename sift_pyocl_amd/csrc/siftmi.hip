@@ -183,7 +183,6 @@ struct siftmi_plan {
     hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_last_b = nullptr;
     float last_min = 0, last_max = 0;
     int64_t last_count = 0;
-    size_t tail_lds_set = 64 * 1024;   // dynamic LDS limit already granted to octave_tail_kernel
     std::vector<void *> allocs;
 
     template <class T> int alloc(T **p, size_t nbytes) {
@@ -493,9 +492,18 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
     }
     for (int s = 0; s < 5; s++) { a.taps[s] = p->taps[s].dev; a.ntaps[s] = p->taps[s].n; }
     const size_t lds = tail_lds_bytes(a.o[0].W, a.o[0].H);
-    if (lds > p->tail_lds_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&octave_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        p->tail_lds_set = lds;
+    {
+        // The dynamic-LDS limit of a kernel is a property of the function on a device, not of a plan: keep the largest
+        // value any plan has asked for (a plan of smaller frames must not lower it under a plan of larger ones).
+        static std::mutex mu;
+        static size_t granted[64] = {0};
+        std::lock_guard<std::mutex> g(mu);
+        size_t &have = granted[p->device & 63];
+        if (have < 64 * 1024) have = 64 * 1024;
+        if (lds > have) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&octave_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have = lds;
+        }
     }
     const int kcap = (int)p->kpsize;
     hipLaunchKernelGGL(octave_tail_kernel, dim3((unsigned)a.n), dim3(SIFT_TAIL_THREADS), lds, st, a, p->par.border_dist,

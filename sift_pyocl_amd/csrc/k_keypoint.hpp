@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                                                           const float4 *__restrict__ kp,
                                                           const int *__restrict__ kp_aux, Counters *cnt, int group,
                                                           int kp_capacity, float4 *__restrict__ okp,
-                                                          int *__restrict__ oaux, int out_capacity) {
+                                                          int *__restrict__ oaux, int out_capacity, int team_below) {
     __shared__ OriWaveLds lds_all[4];
     __shared__ double fold[36];
     const int lane = threadIdx.x & 63;
@@ -201,7 +201,14 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         if (lane == 0) slot = atomicAdd(&cnt->n_out, count);
         store_pending(__shfl(slot, 0), count);
     };
-    for (int i = first + wave; i < n; i += nwaves) {
+    // Sparse groups (fewer than team_below keypoints): the four waves of a workgroup take ONE keypoint, each evaluates
+    // every fourth batch of 64 window samples into its own vote masks / pool, and after a workgroup barrier the bin
+    // owners (wave 0, lanes 0-35) add the four pools in batch order -- the same additions in the same order as with a
+    // wave per keypoint, at a quarter of the latency (the launch lasts as long as its slowest keypoint).
+    const bool team = count < team_below;                 // workgroup uniform
+    const int w4 = threadIdx.x >> 6;
+    const int boff = team ? 64 * w4 : 0, bstep = team ? 256 : 64;
+    for (int i = first + (team ? (int)blockIdx.x : wave); i < n; i += (team ? nblocks : nwaves)) {
         const float4 k = kp[i];          // (peak, row, col, sigma)
         const int aux = kp_aux[i];       // detection scale | octave << 8
         const int scale = aux & 0xff, oct = aux >> 8;
@@ -232,14 +239,14 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             return true;
         };
         int nr = 0, nc = 0;
-        bool nvalid = locate(0, nr, nc);
+        bool nvalid = locate(boff, nr, nc);
         GradTaps ntaps = {};
         if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);   // the loads of batch b+1 are issued before batch b is evaluated
-        for (int base = 0; base < total; base += 64) {
+        for (int base = 0; base < total; base += bstep) {         // (workgroup uniform in team form)
             bool valid = nvalid;
             const int r = nr, c = nc;
             const GradTaps taps = ntaps;
-            nvalid = locate(base + 64, nr, nc);
+            nvalid = locate(base + bstep + boff, nr, nc);
             if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);
             int bin = 0;
             float val = 0.0f;
@@ -278,17 +285,40 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 if (valid) L.pool[pos] = val;
             }
             __builtin_amdgcn_wave_barrier();
-            // owners: ordered sum of the segment
-            for (int k0 = 0; k0 < padded; k0 += 4) {
-                const float4 v = pool4[(seg + k0) >> 2];
-                h = h + v.x;
-                h = h + ((k0 + 1 < votes) ? v.y : 0.0f);
-                h = h + ((k0 + 2 < votes) ? v.z : 0.0f);
-                h = h + ((k0 + 3 < votes) ? v.w : 0.0f);
+            if (!team) {
+                // owners: ordered sum of the segment
+                for (int k0 = 0; k0 < padded; k0 += 4) {
+                    const float4 v = pool4[(seg + k0) >> 2];
+                    h = h + v.x;
+                    h = h + ((k0 + 1 < votes) ? v.y : 0.0f);
+                    h = h + ((k0 + 2 < votes) ? v.z : 0.0f);
+                    h = h + ((k0 + 3 < votes) ? v.w : 0.0f);
+                }
+                if (votes) L.mask[lane] = make_uint2(0u, 0u);
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                __syncthreads();
+                if (w4 == 0 && lane < 36) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {                     // the four waves' batches, in raster order
+                        const uint2 mq = lds_all[q].mask[lane];
+                        const int vq = __popc(mq.x) + __popc(mq.y);
+                        const int sq = (int)lds_all[q].mbase[lane];
+                        const float4 *pq = reinterpret_cast<const float4 *>(lds_all[q].pool);
+                        for (int k0 = 0; k0 < vq; k0 += 4) {
+                            const float4 v = pq[(sq + k0) >> 2];
+                            h = h + v.x;
+                            h = h + ((k0 + 1 < vq) ? v.y : 0.0f);
+                            h = h + ((k0 + 2 < vq) ? v.z : 0.0f);
+                            h = h + ((k0 + 3 < vq) ? v.w : 0.0f);
+                        }
+                        if (vq) lds_all[q].mask[lane] = make_uint2(0u, 0u);
+                    }
+                }
+                __syncthreads();
             }
-            if (votes) L.mask[lane] = make_uint2(0u, 0u);
-            __builtin_amdgcn_wave_barrier();
         }
+        if (team && w4 != 0) continue;       // the histogram lives in wave 0
         // six passes of circular [1 1 1]/3 smoothing; hist[35] sees the already updated hist[0].  The reference divides
         // in double, (float)((double)s / 3.0) (orientation_cpu.cl:101-109): for a float s the double quotient lies at
         // least |s| / (24 ulp) away from every float rounding boundary (3 x midpoint is never a float), so the double

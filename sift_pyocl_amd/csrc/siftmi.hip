@@ -106,6 +106,7 @@ struct Options {
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
+    int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
     int desc_dynamic = 1;    // wave-per-keypoint form: keypoints beyond each wave's first are handed out through a device counter
     int split_detect = 0;    // later octaves: detection on its own stream, off the chain of pyramids (interleaved A/B: 512^2 -3 %, 2048^2 / 4096^2 +-1 %, two pipelined 4096^2 lanes +10 %: off)
     int early_pyr = 0;       // enqueue octave 1's pyramid before octave 0's detection / description (A/B: no gain anywhere, 512^2 +2 %)
@@ -522,7 +523,7 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         Scope sc(p, lab, false, 0, st);
         const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
         hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap);
+                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team);
     }
     hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap);
     if (group == 0 && p->overlap) hipEventRecord(p->ev_mark0, st);   // later octaves may start appending now
@@ -735,6 +736,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "split_detect") o.split_detect = v != 0;
     else if (n == "desc_team") o.desc_team = v > 0 ? v : 0;
     else if (n == "desc_dynamic") o.desc_dynamic = v != 0;
+    else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
@@ -1864,7 +1866,7 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
                        par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
-                       o.as<float4>(), oa.as<int>(), (int)capacity);
+                       o.as<float4>(), oa.as<int>(), (int)capacity, 0);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
     int64_t m = hc.n_out < capacity ? hc.n_out : capacity;

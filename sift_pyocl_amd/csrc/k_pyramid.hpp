@@ -225,7 +225,8 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 template <int N, bool NORM, int DT = 0, int TX = 128, int TY = 64, int VR = 8>
 __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                       int W, int H, TapsArg<N> taps,
-                                                      const uint32_t *__restrict__ mm) {
+                                                      const uint32_t *__restrict__ mm,
+                                                      float *__restrict__ half) {   // not null: also out[2y][2x] -> half (the next octave's plane 0)
     using G = BlurGeom<N, TX, TY>;
     static_assert(TX % 4 == 0 && 64 % (TX / 4) == 0, "the H tasks of one row must sit in one wave");
     static_assert(TY % VR == 0, "vertical tasks tile the rows");
@@ -308,6 +309,9 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ i
                     if (gx < W) o[0] = acc[i].x;
                     if (gx + 1 < W) o[1] = acc[i].y;
                 }
+                // octave hand-off (preprocess.cl:267-285) fused into the launch that writes plane 3 (gx is even)
+                if (half && !(gy & 1) && (gy >> 1) < (H >> 1) && (gx >> 1) < (W >> 1))
+                    half[(size_t)(gy >> 1) * (W >> 1) + (gx >> 1)] = acc[i].x;
             }
         }
     }
@@ -567,7 +571,8 @@ template <int N, int NT, int S> struct March2Geom {
 template <int N, bool NORM, int S, int DT = 0, int HW = 2>
 __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                           int W, int H, int nblocks, int last_subs, int rows_out,
-                                                          TapsArg<N> taps, const uint32_t *__restrict__ mm) {
+                                                          TapsArg<N> taps, const uint32_t *__restrict__ mm,
+                                                          float *__restrict__ next0) {   // not null: also out[2y][2x] -> next0 (the next octave's plane 0)
     constexpr int NT = 128;                       // threads per team
     using G = March2Geom<N, NT, S>;
     using SS = SubSplit<N, S>;
@@ -728,6 +733,8 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
                         if (y >= ys && y < yend && !((BLUR_ABL & 8) && acc[done].x != 12345.678f)) {        \
                             if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];                     \
                             else { if (gxo < W) optr[0] = acc[done].x; if (gxo + 1 < W) optr[1] = acc[done].y; } \
+                            if (next0 && !(y & 1) && (y >> 1) < (H >> 1) && (gxo >> 1) < (W >> 1))           \
+                                next0[(size_t)(y >> 1) * (W >> 1) + (gxo >> 1)] = acc[done].x;              \
                         }                                                                                    \
                         optr += W;                                                                           \
                     }                                                                                        \

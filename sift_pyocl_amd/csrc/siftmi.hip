@@ -106,6 +106,7 @@ struct Options {
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
+    int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)
     int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
     int desc_dynamic = 1;    // wave-per-keypoint form: keypoints beyond each wave's first are handed out through a device counter
     int split_detect = 0;    // later octaves: detection on its own stream, off the chain of pyramids (interleaved A/B: 512^2 -3 %, 2048^2 / 4096^2 +-1 %, two pipelined 4096^2 lanes +10 %: off)
@@ -232,10 +233,10 @@ int compute_schedule(siftmi_plan *p) {
 }
 
 template <int N, bool NORM, int DT, int TX, int TY, int VR>
-void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, const TapsArg<N> &ta, const uint32_t *mm) {
+void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, const TapsArg<N> &ta, const uint32_t *mm, float *half) {
     using G = BlurGeom<N, TX, TY>;
     dim3 grid((unsigned)((W + TX - 1) / TX), (unsigned)((H + TY - 1) / TY));
-    hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT, TX, TY, VR>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm);
+    hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT, TX, TY, VR>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm, half);
 }
 
 // Tile shape.  Planes that reach this kernel are narrower than 1024 columns or shorter than 512 rows (larger ones take
@@ -244,13 +245,13 @@ void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, 
 inline int blur_tile_class(const Options &opt, int, int) { return opt.tile > 0 ? opt.tile : 3; }
 
 template <int N, bool NORM, int DT = 0>
-void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     switch (blur_tile_class(opt, W, H)) {
-        case 1: launch_blur_geom<N, NORM, DT, 128, 64, 8>(st, in, out, W, H, ta, mm); break;
-        case 2: launch_blur_geom<N, NORM, DT, 64, 32, 8>(st, in, out, W, H, ta, mm); break;
-        default: launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm); break;
+        case 1: launch_blur_geom<N, NORM, DT, 128, 64, 8>(st, in, out, W, H, ta, mm, half); break;
+        case 2: launch_blur_geom<N, NORM, DT, 64, 32, 8>(st, in, out, W, H, ta, mm, half); break;
+        default: launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm, half); break;
     }
 }
 
@@ -277,7 +278,7 @@ void launch_march_nt(const Options &opt, hipStream_t st, const void *in, float *
 // sub-blocks (nblocks - 1 full periods + last_subs sub-blocks), so the workgroup count is the one asked for -- 768 for
 // 27 taps on a 4096^2 plane, 3 per CU -- instead of one quantised by segment heights in multiples of N rows (608: 2.4 per CU).
 template <int N, bool NORM, int S, int DT = 0>
-void launch_team(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs) {
+void launch_team(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs, float *half) {
     using G = March2Geom<N, 128, S>;
     using SS = SubSplit<N, S>;
     TapsArg<N> ta;
@@ -299,49 +300,51 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
     const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
     dim3 grid((unsigned)gx, (unsigned)gy);
     hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
-                       rows_out, ta, mm);
+                       rows_out, ta, mm, half);
 }
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
 // plane (tools/ubench/blur_team.hip: 31 / 38 / 41 / 47 / 65 us against 33 / 43 / 45 / 53 / 73 us for the one-block form);
 // option "team" = 0 falls back to the one-block marching kernel.
+// returns whether `half` (the fused octave hand-off) was written: the one-block marching form does not do it
 template <int N, bool NORM, int DT = 0>
-void launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
+bool launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
     if (!opt.team) {
         if (opt.march_nt == 64) launch_march_nt<N, NORM, 64, DT>(opt, st, in, out, W, H, taps, mm);
         else launch_march_nt<N, NORM, 128, DT>(opt, st, in, out, W, H, taps, mm);
-        return;
+        return false;
     }
     constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
-    launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024);
+    launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024, half);
+    return half != nullptr;
 }
 
-// returns false when no tiled instantiation exists for this tap count
+// returns 0 when no tiled instantiation exists for this tap count, 1 when launched, 2 when launched and `half` written
 // The marching kernels amortise their prologue over long strips; measured cross-over with the 32 x 16 tile kernel
 // is near 1400^2 (whole call 0.607 vs 0.609 ms; 1024^2 0.555 vs 0.529, 2048^2 0.732 vs 0.779).
 inline bool march_plane(int W, int H) { return W >= 1024 && H >= 512 && (int64_t)W * H >= 1400 * 1400; }
 
 template <bool NORM>
-bool launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm) {
+int launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm, float *half = nullptr) {
     bool symmetric = true;
     for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
     if (march_plane(W, H) && symmetric && opt.march) {
         switch (t.n) {
-            case 11: launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-            case 15: launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-            case 17: launch_march_t<17, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-            case 21: launch_march_t<21, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-            case 27: launch_march_t<27, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
+            case 11: return launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
+            case 15: return launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
+            case 17: return launch_march_t<17, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
+            case 21: return launch_march_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
+            case 27: return launch_march_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
             default: break;
         }
     }
     switch (t.n) {
-        case 11: launch_blur_t<11, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-        case 15: launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-        case 17: launch_blur_t<17, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-        case 21: launch_blur_t<21, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-        case 27: launch_blur_t<27, NORM>(opt, st, in, out, W, H, t.t, mm); return true;
-        default: return false;
+        case 11: launch_blur_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
+        case 15: launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
+        case 17: launch_blur_t<17, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
+        case 21: launch_blur_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
+        case 27: launch_blur_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
+        default: return 0;
     }
 }
 
@@ -352,11 +355,13 @@ void launch_blur_generic(hipStream_t st, const float *in, float *out, float *tmp
     hipLaunchKernelGGL(blur_generic_pass, grid, dim3(256), 0, st, (const float *)tmp, out, W, H, t.dev, t.n, 1, mm, 0);
 }
 
-void launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm, hipStream_t st = nullptr) {
+// `half` not null: the launch may also write out[2y][2x] there (the next octave's plane 0); returns whether it did
+bool launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm, hipStream_t st = nullptr, float *half = nullptr) {
     if (!st) st = p->stream;
-    bool ok = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm)
-                   : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm);
-    if (!ok) launch_blur_generic(st, in, out, p->tmp, W, H, t, p->mm, norm);
+    const int r = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm, half)
+                       : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm, half);
+    if (!r) launch_blur_generic(st, in, out, p->tmp, W, H, t, p->mm, norm);
+    return r == 2;
 }
 
 bool taps_symmetric(const Taps &t) {
@@ -737,6 +742,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_team") o.desc_team = v > 0 ? v : 0;
     else if (n == "desc_dynamic") o.desc_dynamic = v != 0;
     else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
+    else if (n == "fused_shrink") o.fused_shrink = v != 0;
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
@@ -862,6 +868,7 @@ int enqueue_body(siftmi_plan *p) {
     const bool split = chain0 && p->opt.split_detect;
     auto detect_stream = [&](int oct) { return !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : (split ? p->stream2 : p->stream3)); };   // consumes them
     bool built[SIFT_MAX_OCTAVES] = {false};
+    bool handed[SIFT_MAX_OCTAVES + 1] = {false};   // plane 0 of the octave was written by the blur launch of the octave above
     // shrink + five blurs of one octave on its pyramid stream (once)
     auto build_pyramid = [&](int oct) -> int {
         if (built[oct]) return SIFTMI_OK;
@@ -869,26 +876,33 @@ int enqueue_body(siftmi_plan *p) {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
         hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
         if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
-        if (oct > 0) {
+        if (oct > 0 && !handed[oct]) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
             Scope sc(p, lab, false, 0, pyr);
             hipLaunchKernelGGL(shrink_kernel, shrink_grid(W, H), dim3(256), 0, pyr,
                                (const float *)p->plane(oct - 1, 3), p->plane(oct, 0), LW, W, H);
         }
+        // The octave hand-off (next[y][x] = plane 3 [2y][2x]) rides on the launch that writes plane 3, unless the next octave
+        // is built by the tail kernel (which shrinks for itself) or every stage is bracketed on its own (full profile).
+        // (Across the chain0 hop from octave 0 to 1 the consumer waits for ev_pyr[0], recorded after these launches.)
+        float *half = nullptr;
+        if (p->opt.fused_shrink && p->profile <= 1 && oct + 1 < p->n_oct && oct + 1 != tail_first)
+            half = p->plane(oct + 1, 0);
         if (p->profile == 1) {
             if (oct == 0 && !p->chain) {          // no initial blur: the bracket opens here, five launches
                 Scope *ch = new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0);
                 if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
                 p->chain = ch;
             }
-            for (int s = 0; s < 5; s++) launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr);
+            for (int s = 0; s < 5; s++)
+                if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
             if (oct == 0) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }
         } else {
             for (int s = 0; s < 5; s++) {
                 snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
                 Scope sc(p, lab, true, (double)W * H, pyr, oct);
-                launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr);
+                if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
             }
         }
         if (two && (oct == 0 || pyr != dst)) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));

@@ -45,6 +45,18 @@ __device__ __forceinline__ float dog_at(const BlurPlanes &b, int s, size_t pos) 
 template <int BUF> struct ExtWaveLdsT { float4 buf[BUF + 192]; };
 using ExtWaveLds = ExtWaveLdsT<SIFT_EXT_BUF>;
 
+// what the refinement of a candidate needs besides the planes (refine_candidates below)
+struct RefineArgs {
+    float peak_thresh, init_sigma;
+    float4 *kp;
+    int *kp_aux, *n_kp;
+    int kp_capacity, oct;
+};
+__device__ __forceinline__ void refine_candidates(const BlurPlanes &b, int W, int H, const float4 *__restrict__ cand, int n,
+                                                  float peak_thresh, float init_sigma, float4 *__restrict__ kp,
+                                                  int *__restrict__ kp_aux, int *__restrict__ n_kp, int kp_capacity, int oct,
+                                                  int first, int stride);
+
 // parked candidates [0, count) of a wave -> cand[slot ...]
 template <int BUF>
 __device__ __forceinline__ void ext_store_pending(const ExtWaveLdsT<BUF> &L, float4 *__restrict__ cand, int capacity, int slot, int count, int lane) {
@@ -99,10 +111,19 @@ __device__ __forceinline__ void ext_edge_filter(const BlurPlanes &b, int W, floa
 // convergent).  Extrema are parked in L.buf; `pending` (wave uniform) counts them; a full buffer goes through the edge
 // test and is flushed through one atomicAdd.  What is still parked on return has passed the edge test and is the
 // caller's to flush.
-template <int BUF>
+// REFINE: the survivors of the edge test are refined and appended to the keypoint list right here, one parked entry per
+// lane (no candidate list, no refinement launch); nothing is left parked on return.
+template <int BUF, bool REFINE = false>
 __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H, int border, int rows, bool active, int sx, int sy,
                                               double contrast, float edth, float4 *__restrict__ cand, int *__restrict__ counter,
-                                              int capacity, ExtWaveLdsT<BUF> &L, int &pending) {
+                                              int capacity, ExtWaveLdsT<BUF> &L, int &pending, const RefineArgs *ra = nullptr) {
+    auto refine_parked = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        refine_candidates(b, W, H, L.buf, pending, ra->peak_thresh, ra->init_sigma, ra->kp, ra->kp_aux, ra->n_kp, ra->kp_capacity,
+                          ra->oct, threadIdx.x & 63, 64);
+        __builtin_amdgcn_wave_barrier();
+        pending = 0;
+    };
     const int lane = threadIdx.x & 63;
     const int x = border + sx * 62 + lane - 1;
     const int xc = min(max(x, 0), W - 1);
@@ -190,20 +211,25 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
         if (pending > BUF) {                                 // wave uniform: edge test, then slots for the whole buffer
             ext_edge_filter(b, W, edth, L, tested, pending, lane);
             tested = 0;
-            int slot = 0;
-            if (lane == 0) slot = atomicAdd(counter, pending);
-            ext_store_pending(L, cand, capacity, __shfl(slot, 0), pending, lane);
-            pending = 0;
+            if (REFINE) refine_parked();
+            else {
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(counter, pending);
+                ext_store_pending(L, cand, capacity, __shfl(slot, 0), pending, lane);
+                pending = 0;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) ctr[k] = ctr_next[k];
     }
     ext_edge_filter(b, W, edth, L, tested, pending, lane);
+    if (REFINE) refine_parked();
 }
 
+template <bool REFINE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
                                                       float edth, float4 *__restrict__ cand,
-                                                      int *__restrict__ counter, int capacity) {
+                                                      int *__restrict__ counter, int capacity, RefineArgs ra) {
     __shared__ ExtWaveLds lds_all[4];
     __shared__ int s_pending[4], s_base;
     const int lane = threadIdx.x & 63;
@@ -213,7 +239,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WA
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
     int pending = 0;                                     // candidates parked in L.buf (wave uniform)
-    extrema_strip(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand, counter, capacity, L, pending);
+    extrema_strip<SIFT_EXT_BUF, REFINE>(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand,
+                                        counter, capacity, L, pending, &ra);
+    if (REFINE) return;                                  // every survivor is already in the keypoint list
     // ---- what is left leaves with one atomicAdd per workgroup
     if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
     __syncthreads();

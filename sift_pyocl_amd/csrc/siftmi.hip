@@ -106,6 +106,7 @@ struct Options {
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
+    int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
     int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)
     int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
     int desc_dynamic = 1;    // wave-per-keypoint form: keypoints beyond each wave's first are handed out through a device counter
@@ -449,10 +450,22 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
         const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
         const int blocks = (nx * ny + 3) / 4;
         const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
+        const RefineArgs ra = {p->par.peak_thresh, (float)p->par.init_sigma, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, oct};
+        // One launch detects and refines (the survivors of the edge test are refined by the wave that parked them: no
+        // candidate list, no second launch) unless every stage is bracketed on its own (full profile) or option
+        // "fused_refine" says otherwise (0: never, 1: planes below 1400^2, 2: every plane).
+        const bool fused = p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
+        if (fused) {
+            snprintf(lab, sizeof lab, "local_maxmin+interp_keypoint %d", oct);
+            Scope sc(p, lab, false, 0, st);
+            hipLaunchKernelGGL(extrema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                               contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra);
+            return;
+        }
         snprintf(lab, sizeof lab, "local_maxmin %d", oct);
         Scope sc(p, lab, false, 0, st);
-        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap);
+        hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra);
     }
     {
         snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
@@ -743,6 +756,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_dynamic") o.desc_dynamic = v != 0;
     else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
     else if (n == "fused_shrink") o.fused_shrink = v != 0;
+    else if (n == "fused_refine") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fused_refine must be 0, 1 or 2"); o.fused_refine = (int)v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
@@ -1784,8 +1798,8 @@ int siftmi_stage_local_maxmin(int32_t dev, const float *blurs, int32_t W, int32_
         const int rows = extrema_strip_rows(W, H, border);
         const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
         const float edth = (octsize <= 1) ? par->edge_thresh0 : par->edge_thresh;
-        hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border, rows,
-                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity);
+        hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border, rows,
+                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity, RefineArgs{});
     }
     if ((rc = stage_end())) return rc;
     Counters hc;

@@ -86,7 +86,7 @@ int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsiz
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Names: "fused_convert", "overlap", "march",
- * "team", "march_nt", "march_wgs", "march_nb", "ori_blocks", "ori_pad", "desc_blocks", "desc_pad", "desc_stream", "mm_blocks", "chain0", "tile", "ext_rows", "tail", "early_pyr", "split_detect", "desc_team", "desc_dynamic", "desc_dense_blocks", "ori_team", "fused_shrink", "fused_refine", "spin",
+ * "team", "march_nt", "march_wgs", "march_nb", "ori_blocks", "ori_pad", "desc_blocks", "desc_pad", "desc_stream", "mm_blocks", "chain0", "tile", "ext_rows", "tail", "tail_pixels", "early_pyr", "split_detect", "desc_team", "desc_dynamic", "desc_dense_blocks", "ori_team", "fused_shrink", "fused_refine", "spin",
  * "host_timing".  Unknown name -> SIFTMI_EINVAL. */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 /* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from

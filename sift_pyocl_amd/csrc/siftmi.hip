@@ -112,6 +112,7 @@ struct Options {
     int desc_dynamic = 1;    // wave-per-keypoint form: keypoints beyond each wave's first are handed out through a device counter
     int split_detect = 0;    // later octaves: detection on its own stream, off the chain of pyramids (interleaved A/B: 512^2 -3 %, 2048^2 / 4096^2 +-1 %, two pipelined 4096^2 lanes +10 %: off)
     int early_pyr = 0;       // enqueue octave 1's pyramid before octave 0's detection / description (A/B: no gain anywhere, 512^2 +2 %)
+    int tail_pixels = SIFT_TAIL_MAX_PIXELS;   // largest plane (W * H) the tail kernel takes
     int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
     int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
@@ -489,7 +490,7 @@ int tail_first_octave(const siftmi_plan *p) {
     int first = p->n_oct;
     for (int o = last; o >= 1; o--) {
         const int W = p->ow[(size_t)o], H = p->oh[(size_t)o];
-        if ((int64_t)W * H > SIFT_TAIL_MAX_PIXELS || W > 128 || H > 128 || last - o + 1 > SIFT_TAIL_MAX_OCT) break;
+        if ((int64_t)W * H > p->opt.tail_pixels || W > 128 || H > 128 || last - o + 1 > SIFT_TAIL_MAX_OCT) break;
         first = o;
     }
     return first;
@@ -750,6 +751,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "tile") o.tile = (int)v;
     else if (n == "ext_rows") o.ext_rows = (int)v;
     else if (n == "tail") o.tail = v != 0;
+    else if (n == "tail_pixels") { if (v < 1 || v > SIFT_TAIL_MAX_PIXELS) return fail(SIFTMI_EINVAL, "tail_pixels must be in 1..%d", SIFT_TAIL_MAX_PIXELS); o.tail_pixels = (int)v; }
     else if (n == "early_pyr") o.early_pyr = v != 0;
     else if (n == "split_detect") o.split_detect = v != 0;
     else if (n == "desc_team") o.desc_team = v > 0 ? v : 0;

@@ -62,7 +62,7 @@ template <bool INTERIOR>
 __device__ __forceinline__ void descriptor_sample(const float *__restrict__ I, int W, int H, int x, int y, float rx, float cx,
                                                   float angle, const double *fold, int (&cbin)[8], float (&cval)[8]) {
     float gx, gy;
-    const unsigned pos = (unsigned)y * (unsigned)W + (unsigned)x;     // planes hold < 2^31 pixels (siftmi_plan_create)
+    const unsigned pos = (unsigned)y * (unsigned)W + (unsigned)x;     // planes hold <= 2^30 pixels (siftmi_plan_create)
     if (INTERIOR) {
         gx = I[pos + 1u] - I[pos - 1u];
         gy = I[pos - (unsigned)W] - I[pos + (unsigned)W];

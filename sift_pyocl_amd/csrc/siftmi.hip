@@ -602,7 +602,8 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!out || !params) return fail(SIFTMI_EINVAL, "null argument");
     *out = nullptr;
     if (height < 1 || width < 1) return fail(SIFTMI_EINVAL, "bad shape %dx%d", height, width);
-    if ((int64_t)height * width > (int64_t)1 << 31) return fail(SIFTMI_EINVAL, "image too large");
+    // planes are addressed with 32-bit byte offsets in the extrema kernel and 32-bit sample indices in the window kernels
+    if ((int64_t)height * width > (int64_t)1 << 30) return fail(SIFTMI_EINVAL, "image too large: at most 2^30 pixels (32768 x 32768)");
     if (dtype_size(in_dtype) == 0) return fail(SIFTMI_EINVAL, "invalid input format (%d)", in_dtype);
     if (params->pix_per_kp < 1) return fail(SIFTMI_EINVAL, "pix_per_kp must be >= 1");
     if (params->border_dist < 1) return fail(SIFTMI_EINVAL, "border_dist must be >= 1");

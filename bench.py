@@ -301,7 +301,9 @@ def main():
         plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, devicetype="GPU", device=local_rank, profile="light",
                            octave_max=octaves or None)
         n_oct = plan.octave_max
-        n_img = min(max(K, 1), 8)
+        # distinct frames in rotation: every one of them is seen by the warm-up steps (the first call on a new device
+        # buffer costs ~80 us more than the following ones, whatever the cause -- it is not part of a steady-state step)
+        n_img = max(1, min(K, 8, W if W > 0 else 1))
         dev_images = [torch.from_numpy(make_image(rank * 1000 + i, size)).cuda() for i in range(n_img)]
         torch.cuda.synchronize()
 

@@ -374,13 +374,18 @@ def main():
             # HBM traffic per full-resolution blur launch: not observable from inside this process -- replayed from the
             # committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, tools/summarize_prof.py)
             traffic, traffic_src = None, None
-            for rel in ("profiles/r02/blur_traffic.json", "profiles/blur_traffic.json"):
+            for rel in ("profiles/r03/blur_traffic.json",):
                 tfile = os.path.join(ROOT, rel)
                 if os.path.exists(tfile) and size == SIZE and result["n_oct"] == OCTAVES:
                     try:
-                        traffic = round(json.load(open(tfile))["traffic_bytes_per_launch"], 1)
-                        traffic_src = "replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % rel
-                        break
+                        tj = json.load(open(tfile))
+                        # only a summary that covers all six full-resolution launches of every image of its run counts
+                        if tj.get("complete") and tj["launches_fetch_pass"] == 6 * tj["images_fetch_pass"] \
+                                and tj["launches_write_pass"] == 6 * tj["images_write_pass"]:
+                            traffic = round(tj["traffic_bytes_per_launch"], 1)
+                            traffic_src = ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %d + %d "
+                                           "launches = 6 per image; not observed in this run)" % (rel, tj["launches_fetch_pass"], tj["launches_write_pass"]))
+                            break
                     except Exception:
                         traffic = None
             pipe_gbs = (bytes_alg(size, size, result["n_oct"], result["kp_per_img"]) * K / 1e9) / (kt["tot_ms"] / 1e3) if kt["tot_ms"] > 0 else 0.0

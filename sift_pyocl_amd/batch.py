@@ -317,16 +317,26 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
     mine = shard_indices(len(images), rank, world_size)
     if plan is None and mine:
         plan = BatchPlan(template=images[mine[0]], **plan_kwargs)
-    on_device = (gather and world_size > 1 and isinstance(plan, BatchPlan) and dist.is_initialized()
-                 and dist.get_backend() == "nccl")
+    # The exchange path must be the same on every rank, so it is chosen from rank-independent facts only: the backend
+    # and the kind of plan the caller passed (a rank that owns no frame has no plan at all: plan is None there).
+    nccl = gather and world_size > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
+    on_device = nccl and (plan is None or isinstance(plan, BatchPlan))
     if on_device:
-        counts, records = plan.keypoints_batch_device([images[i] for i in mine])
+        import torch
+        if plan is not None:
+            counts, records = plan.keypoints_batch_device([images[i] for i in mine])
+        else:                                # empty shard (fewer frames than ranks): joins the collectives with nothing
+            counts = []
+            records = torch.empty(0, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
         all_counts, gathered = gather_records_device(counts, records, len(images), rank, world_size)
         return split_gathered(all_counts, gathered, len(images), world_size)
+    if nccl and device is None:              # frame-by-frame SiftPlan under RCCL: the collectives need device tensors
+        import torch
+        device = torch.device("cuda", torch.cuda.current_device())
     if isinstance(plan, BatchPlan):
         local = plan.keypoints_batch([images[i] for i in mine])
     else:
-        local = [plan.keypoints(images[i]) for i in mine]
+        local = [plan.keypoints(images[i]) for i in mine] if mine else []
     if not gather or world_size == 1:
         if world_size == 1:
             return local

@@ -18,11 +18,22 @@
 //  2. EVALUATION.  64 consecutive ranks at a time, one sample per lane: gradient magnitude / orientation from
 //     blur[scale] (image.cl:58-77), Gaussian weight, the eight (bin, value) contributions.  atan2 / exp go through the
 //     Ziv fast paths of siftmath.hpp (bit-identical to the defining functions).
-//  3. ORDERED ACCUMULATION.  Lane l owns bins l and l + 64.  Every sample lane sets its bit in the 64-bit "who
-//     contributes" mask of each bin it touches (LDS atomic OR: order independent); a wave prefix sum of the per-bin
-//     counts (DPP, no LDS round trip) gives every bin a 16-byte aligned segment of a value pool; each sample lane stores
-//     each value at segment base + (number of lower lanes contributing to the same bin); the owner adds its segment
-//     front to back (four values per LDS read): ascending lane == raster order.
+//  3. ORDERED ACCUMULATION.  Lane l owns bins l and l + 64.
+//     a. A sample lane sets its bit in S[half of the wave][cell * 8 + o] for each of its (up to four) cells, o being the
+//        lower of its two orientation bins: one 32-bit LDS atomic OR per cell (order independent).
+//     b. The owner of bin (cell, ob) forms the bin's 64-bit contributor mask S[ob] | S[ob - 1] (a sample reaches ob as
+//        its lower or as its upper orientation bin), counts it, and a wave prefix sum of the counts (DPP, no LDS round
+//        trip) gives every bin a 16-byte aligned segment of a value pool; the owner publishes a 16-byte ENTRY: the mask
+//        and the LDS address of the segment.
+//     c. Each sample lane reads the entries of its eight bins and stores each value at segment + 4 * (number of lower
+//        lanes in the mask): ascending lane == raster order.
+//     d. The owner adds its segments front to back, four values per LDS read.
+//     A cell that does not exist (outside the 4 x 4 grid, or no sample in the lane) is aimed at a private dummy word
+//     (a.) and at ONE shared dummy entry whose mask is all ones (c.: rank == lane, so every lane lands in its own dump
+//     slot): the routing code has no validity tests or exec-masked blocks, only the address selects.
+//     (PMC, round 3, profiles/r03: 70 % of the kernel's VALU instructions were integer / select / move instructions of
+//     this bookkeeping and binary64 6 %; with those cut the LDS became the pole -- 16-byte entries put every cell's
+//     bins on the same eight bank groups -- hence word arrays for the atomics and one atomic per cell, not per bin.)
 //  4. Normalise / clamp 0.2 / renormalise / quantise with the reference's sequential 128-term sums.
 //
 // Windows with more than 2 * SIFT_DESC_MAXRAD + 1 rows are left to descriptor_stream_kernel (a plan cannot produce them:
@@ -39,15 +50,68 @@ namespace siftk {
 #define SIFT_DESC_WAVES 4      // 128 VGPRs, no scratch: 4.03 ms against 4.44 ms at 5 waves (96 VGPRs, 76 B of scratch) on 154 k keypoints
 #endif
 
-struct alignas(16) DescRowLds {
+typedef float desc_f2 __attribute__((ext_vector_type(2)));
+
+struct alignas(16) DescEntry { unsigned mlo, mhi, seg, spare; };     // contributor mask (lanes 0-31 / 32-63), LDS byte address of the first contributor's pool slot
+#define SIFT_DESC_DUMMY 128                    // entry [128]: the shared dummy {~0, ~0, dump slots}: a lane's rank in it is its lane number
+struct alignas(16) DescPool {
     float pool[1024];                          // [0, 896): <= 512 values, every bin's segment zero-padded to a multiple of 4;
-                                               // [896, 900): zeros, read by an owner past the end of its segment; [960 + lane]: dump slots
-    float V[128];
-    uint2 mask[128];                           // per bin: 64-bit mask of contributing lanes (x: lanes 0-31, y: lanes 32-63)
-    unsigned mbase[128];                       // per bin: pool position of the first contributor
+                                               // [896, 900): zeros, read by an owner past its segment; [960 + lane]: dump slots
+    DescEntry ent[SIFT_DESC_DUMMY + 1];        // published by the owners every batch
+    unsigned S[2][128];                        // [half][cell * 8 + o]: lanes of that half with a sample in `cell`, lower orientation bin o
+    unsigned Sdummy[64];                       // lane l's private word for the cells that do not exist (never read)
+};
+struct alignas(16) DescRowLds {
+    DescPool P;                                // P.pool doubles as the 128 squares of the normalisation (step 4)
     int row_start[2 * SIFT_DESC_MAXRAD + 4];   // exclusive prefix of the per-row run lengths; [S] = total
     short row_jlo[2 * SIFT_DESC_MAXRAD + 4];   // first in-window jj of every row
 };
+
+__device__ __forceinline__ unsigned desc_lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // LDS byte address of a __shared__ object
+__device__ __forceinline__ void desc_pool_init(DescPool &P, int lane) {
+    P.S[0][lane] = 0u; P.S[0][lane + 64] = 0u; P.S[1][lane] = 0u; P.S[1][lane + 64] = 0u;
+    P.Sdummy[lane] = 0u;
+    if (lane == 0) *reinterpret_cast<uint4 *>(&P.ent[SIFT_DESC_DUMMY]) = make_uint4(~0u, ~0u, desc_lds_addr(&P.pool[960]), 0u);
+    if (lane < 4) P.pool[896 + lane] = 0.0f;
+}
+
+// LDS objects are addressed by their 32-bit byte address (the low half of the generic address of a __shared__ object):
+// a pointer kept in registers or selected against another one would be a 64-bit generic pointer and every access a
+// flat_* instruction.  The constant part of an address (which of the four cells) rides in the instruction's offset field.
+typedef unsigned desc_u4v __attribute__((ext_vector_type(4)));
+typedef float desc_f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned desc_lds_u32;
+typedef __attribute__((address_space(3))) const desc_u4v desc_lds_u4;
+typedef __attribute__((address_space(3))) float desc_lds_f32;
+typedef __attribute__((address_space(3))) desc_f4v desc_lds_f4;
+template <int K> __device__ __forceinline__ void desc_or32(unsigned addr, unsigned bits) {
+    (void)__hip_atomic_fetch_or(reinterpret_cast<desc_lds_u32 *>(addr + K), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int K> __device__ __forceinline__ uint4 desc_entry(unsigned addr) {
+    const desc_u4v v = *reinterpret_cast<desc_lds_u4 *>(addr + K);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// offsets of the four cells (rb, cb), (rb, cb + 1), (rb + 1, cb), (rb + 1, cb + 1) from the first, in bins (8 per cell)
+#define SIFT_DESC_C0 0
+#define SIFT_DESC_C1 8
+#define SIFT_DESC_C2 32
+#define SIFT_DESC_C3 40
+
+// what a lane needs to address its wave's routing tables
+struct DescRoute {
+    unsigned ent;       // LDS address of entry 0
+    unsigned dummy;     // ... of the shared dummy entry
+    unsigned S;         // ... of S[this lane's half][0]
+    unsigned Sdummy;    // ... of the lane's private word
+    unsigned bit;       // 1 << (lane & 31)
+};
+__device__ __forceinline__ DescRoute desc_route_of(DescPool &P, int lane) {
+    DescRoute r;
+    r.ent = desc_lds_addr(&P.ent[0]); r.dummy = desc_lds_addr(&P.ent[SIFT_DESC_DUMMY]);
+    r.S = desc_lds_addr(&P.S[lane >> 5][0]); r.Sdummy = desc_lds_addr(&P.Sdummy[lane]);
+    r.bit = 1u << (lane & 31);
+    return r;
+}
 
 // next representable float towards +inf (up) or -inf, x finite and non-zero
 __device__ __forceinline__ float f32_neighbour(float x, bool up) {
@@ -55,59 +119,228 @@ __device__ __forceinline__ float f32_neighbour(float x, bool up) {
     return __int_as_float(((b >= 0) == up) ? b + 1 : b - 1);
 }
 
-// One sample of the descriptor window: everything keypoints_cpu.cl:74-117 does for it, except the additions.
-// cbin[n] < 0: no contribution.  INTERIOR: the whole window lies at least one pixel inside the plane (no one-sided
-// differences, image.cl:58-77).
+// what is the same for every sample of a keypoint's window (wave uniform)
+struct DescWindow {
+    const float *I;            // blur[scale] of the keypoint's octave
+    unsigned W4;               // row pitch in bytes
+    int W, H, irow, icol;
+    float sine, cosine, drow, dcol, spacing, rspacing, angle;
+    bool fast_div, interior;
+};
+
+// The four neighbours a sample's gradient needs (image.cl:58-77), fetched one batch ahead of their use: the loads of
+// batch b + 1 are in flight while batch b is evaluated and accumulated (a wave runs its batches one after the other and
+// only four waves share a SIMD: what a wave does not overlap itself is not overlapped).
+struct DescSample { int ii, jj; float right, left, up, down; };
 template <bool INTERIOR>
-__device__ __forceinline__ void descriptor_sample(const float *__restrict__ I, int W, int H, int x, int y, float rx, float cx,
-                                                  float angle, const double *fold, int (&cbin)[8], float (&cval)[8]) {
-    float gx, gy;
-    const unsigned pos = (unsigned)y * (unsigned)W + (unsigned)x;     // planes hold <= 2^30 pixels (siftmi_plan_create)
+__device__ __forceinline__ void desc_fetch(const DescWindow &w, int ii, int jj, DescSample &q) {
+    // loads address the plane as scalar base + 32-bit byte offset
+    const int x = w.icol + jj, y = w.irow + ii;
+    const unsigned off = __umul24((unsigned)y, w.W4) + ((unsigned)x << 2);   // planes hold <= 2^30 pixels, rows <= 2^22 bytes
+    auto ld = [&](unsigned o) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(w.I) + o); };
+    q.ii = ii; q.jj = jj;
     if (INTERIOR) {
-        gx = I[pos + 1u] - I[pos - 1u];
-        gy = I[pos - (unsigned)W] - I[pos + (unsigned)W];
+        q.right = ld(off + 4u); q.left = ld(off - 4u); q.up = ld(off - w.W4); q.down = ld(off + w.W4);
     } else {
-        const bool bx = (x == 0) || (x == W - 1), by = (y == 0) || (y == H - 1);
-        gx = I[x == W - 1 ? pos : pos + 1u] - I[x == 0 ? pos : pos - 1u];
-        gy = I[y == 0 ? pos : pos - (unsigned)W] - I[y == H - 1 ? pos : pos + (unsigned)W];
-        if (bx) gx = 2.0f * gx;
-        if (by) gy = 2.0f * gy;
+        q.right = ld(x == w.W - 1 ? off : off + 4u); q.left = ld(x == 0 ? off : off - 4u);
+        q.up = ld(y == 0 ? off : off - w.W4); q.down = ld(y == w.H - 1 ? off : off + w.W4);
+    }
+}
+
+// One sample of the descriptor window: everything keypoints_cpu.cl:74-117 does for it, except the additions.
+// tgs[c] (+ the cell's constant): LDS address of the S word of cell c; tgt[n] (+ the cell's constant): LDS address of
+// the entry of the bin contribution n goes to, cval[n] its value; the dummies where the cell does not exist or the lane
+// is not `live`.
+// INTERIOR: the whole window lies at least one pixel inside the plane (no one-sided differences, image.cl:58-77).
+template <bool INTERIOR>
+__device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample &q, bool live, const double *fold, const DescRoute &rt,
+                                          unsigned (&tgs)[4], unsigned (&tgt)[8], float (&cval)[8]) {
+    // ---- window coordinates (keypoints_cpu.cl:64-67): rx = ((cos*i - sin*j) - drow) / spacing + 1.5, cx likewise.
+    //      Both at once in packed-f32 instructions: -(cos*j) == (-cos)*j exactly, so uc = sin*i - (-cos)*j.
+    const int ii = q.ii, jj = q.jj;
+    const float fi = (float)ii, fj = (float)jj;
+    const desc_f2 A = (desc_f2){w.cosine, w.sine} * (desc_f2){fi, fi};
+    const desc_f2 B = (desc_f2){w.sine, -w.cosine} * (desc_f2){fj, fj};
+    const desc_f2 U = (A - B) - (desc_f2){w.drow, w.dcol};
+    desc_f2 Q;
+    if (w.fast_div) {          // Markstein: the correctly rounded quotient from the correctly rounded reciprocal (siftmath.hpp)
+        const desc_f2 rb = {w.rspacing, w.rspacing}, nb = {-w.spacing, -w.spacing};
+        Q = U * rb;
+        desc_f2 r = __builtin_elementwise_fma(nb, Q, U);
+        Q = __builtin_elementwise_fma(r, rb, Q);
+        r = __builtin_elementwise_fma(nb, Q, U);
+        Q = __builtin_elementwise_fma(r, rb, Q);
+    } else {
+        Q = (desc_f2){U.x / w.spacing, U.y / w.spacing};
+    }
+    const desc_f2 RC = Q + (desc_f2){1.5f, 1.5f};
+    const float rx = RC.x, cx = RC.y;
+
+    // ---- gradient of blur[scale] at the sample (image.cl:58-77)
+    float gx = q.right - q.left, gy = q.up - q.down;
+    if (!INTERIOR) {
+        const int x = w.icol + jj, y = w.irow + ii;
+        if ((x == 0) || (x == w.W - 1)) gx = 2.0f * gx;
+        if ((y == 0) || (y == w.H - 1)) gy = 2.0f * gy;
     }
     const float g = sqrtf(gx * gx + gy * gy);
-    float o = siftmath::atan2f_fast(-gy, gx, fold);
-    const float er = rx - 1.5f, ec = cx - 1.5f;
-    const float mag = g * siftmath::expf_fast(-0.125f * (er * er + ec * ec));
-    o = o - angle;
+    const desc_f2 E = RC - (desc_f2){1.5f, 1.5f};
+    const desc_f2 E2 = E * E;
+    const float earg = -0.125f * (E2.x + E2.y);
+    // the two Ziv candidates in one basic block (two independent binary64 chains side by side), one branch for both
+    bool ok_a, ok_e;
+    float o = siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
+    float ew = siftmath::expf_fast_try(earg, ok_e);
+    if (!(ok_a && ok_e)) {                        // 2^-14 of the samples: the defining functions
+        if (!ok_a) o = siftmath::atan2f_(-gy, gx);
+        if (!ok_e) ew = siftmath::expf_(earg);
+    }
+    const float mag = g * ew;
+    o = o - w.angle;
     while (o > 2.0f * SM_PI_F) o -= 2.0f * SM_PI_F;
     while (o < 0.0f) o += 2.0f * SM_PI_F;
     const float oval = 4.0f * o * SM_1_PI_F;
     const int ri = (int)((rx >= 0.0f) ? rx : rx - 1.0f);
     const int ci = (int)((cx >= 0.0f) ? cx : cx - 1.0f);
     const int oi = (int)((oval >= 0.0f) ? oval : oval - 1.0f);
-    const float rf = rx - (float)ri, cf = cx - (float)ci, of = oval - (float)oi;
-    const bool contributes = ri >= -1 && ri < 4 && oi >= 0 && oi <= 8 && rf >= 0.0f && rf <= 1.0f;
+    const desc_f2 F = RC - (desc_f2){(float)ri, (float)ci};
+    const float rf = F.x, cf = F.y, of = oval - (float)oi;
+    const desc_f2 G = (desc_f2){1.0f, 1.0f} - F;
+    const bool contributes = live && ri >= -1 && ri < 4 && oi >= 0 && oi <= 8 && rf >= 0.0f && rf <= 1.0f;
+    // the eight values, products in the reference's order: ((mag * row weight) * column weight) * orientation weight
+    const desc_f2 RW = (desc_f2){mag, mag} * (desc_f2){G.x, rf};                 // a = 0, 1
+    const desc_f2 CWa = (desc_f2){RW.x, RW.x} * (desc_f2){G.y, cf};              // a = 0: bb = 0, 1
+    const desc_f2 CWb = (desc_f2){RW.y, RW.y} * (desc_f2){G.y, cf};              // a = 1
+    const desc_f2 OW = {1.0f - of, of};
+    const desc_f2 v00 = (desc_f2){CWa.x, CWa.x} * OW, v01 = (desc_f2){CWa.y, CWa.y} * OW;
+    const desc_f2 v10 = (desc_f2){CWb.x, CWb.x} * OW, v11 = (desc_f2){CWb.y, CWb.y} * OW;
+    // the eight bins (rb * 4 + cb) * 8 + ob.  Orientation bin oi + 1 wraps to 0; oi == 8 happens only for oval == 8.0f
+    // exactly (o == 2*pi_f), where of == 0: e = 0 adds cw*1 to bin 0, e = 1 would add cw*0 == +0 to bin 0 again (no
+    // effect on a non-negative sum); here such a sample counts as one of orientation bin 0 whose upper value is +0.
+    const bool nd = oi != 8;
+    cval[0] = v00.x; cval[1] = nd ? v00.y : 0.0f; cval[2] = v01.x; cval[3] = nd ? v01.y : 0.0f;
+    cval[4] = v10.x; cval[5] = nd ? v10.y : 0.0f; cval[6] = v11.x; cval[7] = nd ? v11.y : 0.0f;
+    const unsigned c00 = (unsigned)((ri * 4 + ci) * 8);                          // first bin of the cell (used where it exists)
+    const unsigned o0 = (unsigned)(oi & 7), o1 = (unsigned)((oi + 1) & 7);
+    const unsigned s0 = rt.S + 4u * (c00 + o0);
+    const unsigned t0 = rt.ent + 16u * (c00 + o0), t1 = rt.ent + 16u * (c00 + o1);
+    const bool r0 = contributes && ri >= 0, r1 = contributes && ri < 3;          // rb = ri, ri + 1 in 0..3
+    const bool k0 = ci >= 0 && ci < 4, k1 = ci >= -1 && ci < 3;                  // cb = ci, ci + 1 in 0..3
+    const bool v0 = r0 && k0, v1 = r0 && k1, v2 = r1 && k0, v3 = r1 && k1;
+    tgs[0] = v0 ? s0 : rt.Sdummy - 4u * SIFT_DESC_C0;   tgs[1] = v1 ? s0 : rt.Sdummy - 4u * SIFT_DESC_C1;
+    tgs[2] = v2 ? s0 : rt.Sdummy - 4u * SIFT_DESC_C2;   tgs[3] = v3 ? s0 : rt.Sdummy - 4u * SIFT_DESC_C3;
+    tgt[0] = v0 ? t0 : rt.dummy - 16u * SIFT_DESC_C0;   tgt[1] = v0 ? t1 : rt.dummy - 16u * SIFT_DESC_C0;
+    tgt[2] = v1 ? t0 : rt.dummy - 16u * SIFT_DESC_C1;   tgt[3] = v1 ? t1 : rt.dummy - 16u * SIFT_DESC_C1;
+    tgt[4] = v2 ? t0 : rt.dummy - 16u * SIFT_DESC_C2;   tgt[5] = v2 ? t1 : rt.dummy - 16u * SIFT_DESC_C2;
+    tgt[6] = v3 ? t0 : rt.dummy - 16u * SIFT_DESC_C3;   tgt[7] = v3 ? t1 : rt.dummy - 16u * SIFT_DESC_C3;
+}
+
+// Steps 3a-3c for one batch of a wave.  On return the pool holds every bin's values in lane order; (base, padded counts)
+// of the caller's two bins come back for the owners' sums.
+__device__ __forceinline__ void desc_route(DescPool &P, const DescRoute &rt, const unsigned (&tgs)[4], const unsigned (&tgt)[8],
+                                           const float (&cval)[8], int lane, int &base_a, int &pa, int &pb) {
+    // ---- 3a. one 32-bit LDS atomic per cell
+    desc_or32<4 * SIFT_DESC_C0>(tgs[0], rt.bit); desc_or32<4 * SIFT_DESC_C1>(tgs[1], rt.bit);
+    desc_or32<4 * SIFT_DESC_C2>(tgs[2], rt.bit); desc_or32<4 * SIFT_DESC_C3>(tgs[3], rt.bit);
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3b. bin owners: mask = S[ob] | S[ob - 1] of the cell, counts, 16-byte aligned pool segments from a wave prefix sum
+    const int prev = (lane & ~7) | ((lane + 7) & 7);           // same cell, orientation bin - 1 (bins lane and lane + 64 alike)
+    const unsigned alo = P.S[0][lane] | P.S[0][prev], ahi = P.S[1][lane] | P.S[1][prev];
+    const unsigned blo = P.S[0][lane + 64] | P.S[0][prev + 64], bhi = P.S[1][lane + 64] | P.S[1][prev + 64];
+    const int cnta = __popc(alo) + __popc(ahi), cntb = __popc(blo) + __popc(bhi);
+    pa = (cnta + 3) & ~3; pb = (cntb + 3) & ~3;
+    base_a = wave_prefix_incl(pa + pb) - (pa + pb);
+    const int base_b = base_a + pa;
+    const unsigned pool0 = desc_lds_addr(&P.pool[0]);
+    *reinterpret_cast<uint4 *>(&P.ent[lane]) = make_uint4(alo, ahi, pool0 + 4u * (unsigned)base_a, 0u);
+    *reinterpret_cast<uint4 *>(&P.ent[lane + 64]) = make_uint4(blo, bhi, pool0 + 4u * (unsigned)base_b, 0u);
+    // the last group of four of every segment starts as +0: its padding then adds +0 (an exact no-op on these
+    // non-negative sums), so the owners' loops need no per-element masks
+    if (cnta) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)base_b) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
+    if (cntb) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)(base_b + pb)) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3c. every value to segment start + 4 * rank among the contributors of its bin (mbcnt: set bits of the mask
+    //          below this lane); the eight 16-byte reads are in flight together
+    uint4 e[8];
+    e[0] = desc_entry<16 * SIFT_DESC_C0>(tgt[0]); e[1] = desc_entry<16 * SIFT_DESC_C0>(tgt[1]);
+    e[2] = desc_entry<16 * SIFT_DESC_C1>(tgt[2]); e[3] = desc_entry<16 * SIFT_DESC_C1>(tgt[3]);
+    e[4] = desc_entry<16 * SIFT_DESC_C2>(tgt[4]); e[5] = desc_entry<16 * SIFT_DESC_C2>(tgt[5]);
+    e[6] = desc_entry<16 * SIFT_DESC_C3>(tgt[6]); e[7] = desc_entry<16 * SIFT_DESC_C3>(tgt[7]);
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-        const int rb = ri + a;
-        const float rw = mag * (a == 0 ? 1.0f - rf : rf);
-#pragma unroll
-        for (int bb = 0; bb < 2; bb++) {
-            const int cb = ci + bb;
-            const float cw = rw * (bb == 0 ? 1.0f - cf : cf);
-            const bool ok = contributes && rb >= 0 && rb < 4 && cb >= 0 && cb < 4;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                int ob = oi + e;
-                // oi == 8 only for oval == 8.0f exactly (o == 2*pi_f), where of == 0: e = 0 adds cw*1 to bin 0,
-                // e = 1 would add cw*0 == +0 to bin 0 again (no effect on a non-negative sum) -> skipped.
-                const bool dup = (e == 1 && oi == 8);
-                if (ob >= 8) ob = 0;
-                const int n8 = a * 4 + bb * 2 + e;
-                cbin[n8] = (ok && !dup) ? (rb * 4 + cb) * 8 + ob : -1;
-                cval[n8] = cw * (e == 0 ? 1.0f - of : of);
-            }
+    for (int n8 = 0; n8 < 8; n8++)
+        *reinterpret_cast<desc_lds_f32 *>(e[n8].z + 4u * __builtin_amdgcn_mbcnt_hi(e[n8].y, __builtin_amdgcn_mbcnt_lo(e[n8].x, 0u))) = cval[n8];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// after the owners' sums: the S words of the caller's two bins are cleared for the next batch
+__device__ __forceinline__ void desc_route_reset(DescPool &P, int lane) {
+    P.S[0][lane] = 0u; P.S[1][lane] = 0u; P.S[0][lane + 64] = 0u; P.S[1][lane + 64] = 0u;
+}
+
+// the owner's ordered sum of one segment (n4 groups of four, the first at pool4[q]); reads run one group ahead -- the
+// group after the last one of a segment is another segment's or the zeros at [896], in bounds either way
+__device__ __forceinline__ float desc_sum_segment(const float4 *pool4, int q, int n4, float acc) {
+    if (n4 > 0) {
+        float4 v = pool4[q];
+        for (int g4 = 0; g4 < n4; g4++) {
+            const float4 c = v;
+            v = pool4[q + g4 + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = acc + c.x; acc = acc + c.y; acc = acc + c.z; acc = acc + c.w;
         }
     }
+    return acc;
+}
+
+// The ordered sums of a lane's two bins (adjacent segments: a at group qa, then b).  A bin receives 2.6 values per batch
+// on average and rarely more than eight: the first two groups of both chains are read together (one LDS round trip for
+// both sums of nearly every lane; a lane past its segment reads the four zeros at group 224: +0 is an exact no-op on
+// these non-negative sums), the rest -- if any lane of the wave has one -- in a loop with one read in flight per chain.
+__device__ __forceinline__ void desc_sum_pair(const float4 *pool4, int qa, int ea, int eb, float &acc0, float &acc1) {
+    const int qb = qa + ea;
+    const float4 a0 = pool4[ea > 0 ? qa : 224], a1 = pool4[ea > 1 ? qa + 1 : 224];
+    const float4 b0 = pool4[eb > 0 ? qb : 224], b1 = pool4[eb > 1 ? qb + 1 : 224];
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = acc0 + a0.x; acc1 = acc1 + b0.x;
+    acc0 = acc0 + a0.y; acc1 = acc1 + b0.y;
+    acc0 = acc0 + a0.z; acc1 = acc1 + b0.z;
+    acc0 = acc0 + a0.w; acc1 = acc1 + b0.w;
+    acc0 = acc0 + a1.x; acc1 = acc1 + b1.x;
+    acc0 = acc0 + a1.y; acc1 = acc1 + b1.y;
+    acc0 = acc0 + a1.z; acc1 = acc1 + b1.z;
+    acc0 = acc0 + a1.w; acc1 = acc1 + b1.w;
+    if (__ballot(ea > 2 || eb > 2)) {                 // wave uniform
+        const int nmax = max(ea, eb);
+        float4 va = pool4[ea > 2 ? qa + 2 : 224], vb = pool4[eb > 2 ? qb + 2 : 224];
+        for (int g4 = 2; g4 < nmax; g4++) {
+            const float4 ca = va, cb = vb;
+            va = pool4[(g4 + 1 < ea) ? qa + g4 + 1 : 224];
+            vb = pool4[(g4 + 1 < eb) ? qb + g4 + 1 : 224];
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = acc0 + ca.x; acc1 = acc1 + cb.x;
+            acc0 = acc0 + ca.y; acc1 = acc1 + cb.y;
+            acc0 = acc0 + ca.z; acc1 = acc1 + cb.z;
+            acc0 = acc0 + ca.w; acc1 = acc1 + cb.w;
+        }
+    }
+}
+
+// per-keypoint set-up shared by the two forms: the window's constants from the oriented keypoint
+__device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4 kq, int aux, DescWindow &w, int &R) {
+    const int scale = aux & 0xff, oct = aux >> 8;
+    w.W = tab.W[oct]; w.H = tab.H[oct];
+    w.W4 = (unsigned)w.W * 4u;
+    w.I = tab.base + tab.off[oct] + (size_t)scale * w.W * w.H;
+    const float foct = (float)(1 << oct);
+    const float row = kq.y / foct, col = kq.x / foct;
+    w.angle = kq.w;
+    w.irow = (int)(row + 0.5f); w.icol = (int)(col + 0.5f);
+    siftmath::sincosf_(w.angle, &w.sine, &w.cosine);
+    w.spacing = kq.z / foct * 3.0f;
+    R = (int)((1.414f * w.spacing * 2.5f) + 0.5f);
+    w.drow = row - (float)w.irow; w.dcol = col - (float)w.icol;
+    w.rspacing = 1.0f / w.spacing;
+    w.interior = w.irow - R >= 1 && w.irow + R <= w.H - 2 && w.icol - R >= 1 && w.icol + R <= w.W - 2;
 }
 
 // `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
@@ -119,10 +352,11 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
     siftmath::load_atan_fold(fold);
-    L.mask[lane] = make_uint2(0u, 0u); L.mask[lane + 64] = make_uint2(0u, 0u);
-    if (lane < 4) L.pool[896 + lane] = 0.0f;
+    desc_pool_init(L.P, lane);
     __syncthreads();                     // the only workgroup barrier: the fold table
     const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
+    const DescRoute rt = desc_route_of(L.P, lane);
+    const float4 *pool4 = reinterpret_cast<const float4 *>(L.P.pool);
 
     auto advance = [&](int i) {
         if (!next) return i + nwaves;
@@ -131,25 +365,24 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         return start + nwaves + __builtin_amdgcn_readfirstlane(t);
     };
     for (int i = start + gwave; i < end; i = advance(i)) {
-        const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
-        const int aux = oaux[i];         // detection scale | octave << 8
-        const int scale = aux & 0xff, oct = aux >> 8;
-        const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
+        // the keypoint is the same in every lane: keep its integer attributes in scalar registers
+        float4 kq = okp[i];              // (x, y, sigma*oct, angle)
+        kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
+        kq.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.y)));
+        kq.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.z)));
+        kq.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.w)));
+        const int aux = __builtin_amdgcn_readfirstlane(oaux[i]);         // detection scale | octave << 8
         KpRecord *rec = records + i;
         KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
         if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
-            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.V));
+            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.P.pool));
             continue;
         }
-        const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
-        const float foct = (float)octsize;
-        const float row = kq.y / foct, col = kq.x / foct, angle = kq.w;
-        const int irow = (int)(row + 0.5f), icol = (int)(col + 0.5f);
-        float sine, cosine;
-        siftmath::sincosf_(angle, &sine, &cosine);
-        const float spacing = kq.z / foct * 3.0f;
-        const int R = (int)((1.414f * spacing * 2.5f) + 0.5f);
-        const float drow = row - (float)irow, dcol = col - (float)icol;
+        DescWindow w;
+        int R;
+        desc_window(tab, kq, aux, w, R);
+        const int W = w.W, H = w.H, irow = w.irow, icol = w.icol;
+        const float sine = w.sine, cosine = w.cosine, spacing = w.spacing, drow = w.drow, dcol = w.dcol;
         const int S = 2 * R + 1;
         if (R > SIFT_DESC_MAXRAD) __builtin_trap();   // the host launches descriptor_stream_kernel for such plans
 
@@ -169,6 +402,7 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         }
         auto below_hi = [&](float u) { return thr_ok ? (u < t_hi) : (g(u) < 4.0f); };
         auto above_lo = [&](float u) { return thr_ok ? (u > t_lo) : (g(u) > -1.0f); };
+        w.fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;      // no under / overflow in div_by_reciprocal
 
         // ---- 1b. row intervals: lane l owns the window rows l, l + 64, ...
         const bool rdec = sine >= 0.0f;          // u_r non-increasing in jj
@@ -212,89 +446,32 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         __builtin_amdgcn_wave_barrier();
 
         // ---- 2 + 3. 64 ranks at a time
-        const float rspacing = 1.0f / spacing;
-        const bool fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;      // no under / overflow in div_by_reciprocal
-        const bool interior = irow - R >= 1 && irow + R <= H - 2 && icol - R >= 1 && icol + R <= W - 2;   // wave uniform
-        float4 *pool4 = reinterpret_cast<float4 *>(L.pool);
         float acc0 = 0.0f, acc1 = 0.0f;  // bins lane and lane + 64
         int rcur = 0;                    // row of this lane's current rank (ranks only grow)
+        DescSample nxt;
+        // a lane beyond the last rank evaluates the last sample again, aimed at its dummy entry: no divergence, no
+        // default values to materialise
+        auto fetch = [&](int s0) {
+            const int sc = min(s0 + lane, total - 1);
+            while (sc >= L.row_start[rcur + 1]) rcur++;
+            const int ii = rcur - R, jj = (int)L.row_jlo[rcur] + (sc - L.row_start[rcur]);
+            if (w.interior) desc_fetch<true>(w, ii, jj, nxt);
+            else desc_fetch<false>(w, ii, jj, nxt);
+        };
+        if (total > 0) fetch(0);
         for (int s0 = 0; s0 < total; s0 += 64) {
-            const int s = s0 + lane;
-            int cbin[8];
+            const DescSample cur = nxt;
+            if (s0 + 64 < total) fetch(s0 + 64);     // wave uniform: the next batch's neighbours, in flight during this one
+            unsigned tgs[4], tgt[8];
             float cval[8];
-#pragma unroll
-            for (int n8 = 0; n8 < 8; n8++) { cbin[n8] = -1; cval[n8] = 0.0f; }
-            if (s < total && !ABL(13)) {
-                while (s >= L.row_start[rcur + 1]) rcur++;
-                const int ii = rcur - R, jj = (int)L.row_jlo[rcur] + (s - L.row_start[rcur]);
-                const float ur = (cosine * (float)ii - sine * (float)jj) - drow, uc = (sine * (float)ii + cosine * (float)jj) - dcol;
-                const float rx = (fast_div ? siftmath::div_by_reciprocal(ur, spacing, rspacing) : ur / spacing) + 1.5f;
-                const float cx = (fast_div ? siftmath::div_by_reciprocal(uc, spacing, rspacing) : uc / spacing) + 1.5f;
-                if (ABL(12)) { cbin[0] = (ii * 7 + jj) & 127; cval[0] = rx + cx; }
-                else if (interior) descriptor_sample<true>(I, W, H, icol + jj, irow + ii, rx, cx, angle, fold, cbin, cval);
-                else descriptor_sample<false>(I, W, H, icol + jj, irow + ii, rx, cx, angle, fold, cbin, cval);
-                if (ABL(11)) { acc0 += cval[0] + cval[7] + (float)cbin[3]; continue; }
-            }
-            if (ABL(11) || ABL(13)) continue;
-            // ---- 3a. contributor masks
-            {
-                const unsigned bit = 1u << (lane & 31);
-                unsigned *mw = reinterpret_cast<unsigned *>(L.mask) + (lane >> 5);
-#pragma unroll
-                for (int n8 = 0; n8 < 8; n8++)
-                    if (cbin[n8] >= 0) atomicOr(mw + 2 * cbin[n8], bit);
-            }
+            if (w.interior) desc_eval<true>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
+            else desc_eval<false>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
+            int base_a, pa, pb;
+            desc_route(L.P, rt, tgs, tgt, cval, lane, base_a, pa, pb);
+            // ---- 3d. ordered sums of this lane's two bins
+            desc_sum_pair(pool4, base_a >> 2, pa >> 2, pb >> 2, acc0, acc1);
             __builtin_amdgcn_wave_barrier();
-            // ---- 3b. bin owners: counts, 16-byte aligned pool segments from a wave prefix sum
-            const uint2 ia = L.mask[lane], ib = L.mask[lane + 64];
-            const int cnta = __popc(ia.x) + __popc(ia.y), cntb = __popc(ib.x) + __popc(ib.y);
-            const int pa = (cnta + 3) & ~3, pb = (cntb + 3) & ~3;
-            const int base_a = wave_prefix_incl(pa + pb) - (pa + pb);
-            const int base_b = base_a + pa;
-            L.mbase[lane] = (unsigned)base_a;
-            L.mbase[lane + 64] = (unsigned)base_b;
-            // the last group of four of every segment starts as +0: its padding then adds +0 (an exact no-op on these
-            // non-negative sums), so the owners' loop needs no per-element masks
-            if (cnta) pool4[(base_a + pa - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cntb) pool4[(base_b + pb - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            __builtin_amdgcn_wave_barrier();
-            // ---- 3c. every value to segment base + rank among the contributors of its bin.  Branch free, so that the 16
-            //          LDS reads are in flight together (exec-masked blocks would serialise them); a lane without a
-            //          contribution reads bin 0 and writes to its own dump slot.
-            if (!ABL(15)) {
-                uint2 mk[8];
-                unsigned mb[8];
-#pragma unroll
-                for (int n8 = 0; n8 < 8; n8++) {
-                    const int b = max(cbin[n8], 0);
-                    mk[n8] = L.mask[b];
-                    mb[n8] = L.mbase[b];
-                }
-#pragma unroll
-                for (int n8 = 0; n8 < 8; n8++) {
-                    // mbcnt: number of set bits of the mask below this lane
-                    const int pos = mb[n8] + __builtin_amdgcn_mbcnt_hi(mk[n8].y, __builtin_amdgcn_mbcnt_lo(mk[n8].x, 0u));
-                    L.pool[(cbin[n8] >= 0) ? pos : 960 + lane] = cval[n8];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- 3d. ordered sums, four values per read, the next read in flight while the current four are added; past
-            //          the end of its own segment a lane reads the four zeros at [896]
-            const int nmax = ABL(14) ? 0 : max(pa, pb);
-            const int qa = base_a >> 2, qb = base_b >> 2, ea = pa >> 2, eb = pb >> 2;
-            float4 va = pool4[ea ? qa : 224], vb = pool4[eb ? qb : 224];
-            for (int g4 = 0; g4 < (nmax >> 2); g4++) {
-                const float4 ca = va, cb = vb;
-                va = pool4[(g4 + 1 < ea) ? qa + g4 + 1 : 224];
-                vb = pool4[(g4 + 1 < eb) ? qb + g4 + 1 : 224];
-                acc0 = acc0 + ca.x; acc1 = acc1 + cb.x;
-                acc0 = acc0 + ca.y; acc1 = acc1 + cb.y;
-                acc0 = acc0 + ca.z; acc1 = acc1 + cb.z;
-                acc0 = acc0 + ca.w; acc1 = acc1 + cb.w;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (cnta) L.mask[lane] = make_uint2(0u, 0u);
-            if (cntb) L.mask[lane + 64] = make_uint2(0u, 0u);
+            desc_route_reset(L.P, lane);
             __builtin_amdgcn_wave_barrier();
         }
 
@@ -307,22 +484,22 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
             for (int k8 = 0; k8 < 4; k8++) {
                 float4 q[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) q[u] = reinterpret_cast<const float4 *>(L.V)[8 * k8 + u];
+                for (int u = 0; u < 8; u++) q[u] = reinterpret_cast<const float4 *>(L.P.pool)[8 * k8 + u];
 #pragma unroll
                 for (int u = 0; u < 8; u++) { t = t + q[u].x; t = t + q[u].y; t = t + q[u].z; t = t + q[u].w; }
             }
             return t;
         };
-        L.V[lane] = acc0 * acc0; L.V[lane + 64] = acc1 * acc1;
+        L.P.pool[lane] = acc0 * acc0; L.P.pool[lane + 64] = acc1 * acc1;
         __builtin_amdgcn_wave_barrier();
-        float norm = ABL(16) ? L.V[5] : 1.0f / sqrtf(sum_squares());       // rsqrt
+        float norm = 1.0f / sqrtf(sum_squares());       // rsqrt
         acc0 = acc0 * norm; acc1 = acc1 * norm;
         const bool ch = (acc0 > 0.2f) || (acc1 > 0.2f);
         if (acc0 > 0.2f) acc0 = 0.2f;
         if (acc1 > 0.2f) acc1 = 0.2f;
         __builtin_amdgcn_wave_barrier();
         if (__ballot(ch)) {
-            L.V[lane] = acc0 * acc0; L.V[lane + 64] = acc1 * acc1;
+            L.P.pool[lane] = acc0 * acc0; L.P.pool[lane + 64] = acc1 * acc1;
             __builtin_amdgcn_wave_barrier();
             const float n2 = 1.0f / sqrtf(sum_squares());
             acc0 = acc0 * n2; acc1 = acc1 * n2;
@@ -331,7 +508,7 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see the oracle's note)
         const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
-        store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.V));
+        store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.P.pool));
     }
 }
 
@@ -339,16 +516,11 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
 // The same descriptor, ONE WORKGROUP (four waves) per keypoint: for sparse groups.  With a wave per keypoint a launch
 // lasts as long as its slowest keypoint (60-120 us: ~40-75 batches of 64 samples, one after the other, on a SIMD that
 // has nothing else to issue), however few keypoints there are.  Here the four waves evaluate four consecutive batches
-// at once, each into its own mask / pool area, and after a workgroup barrier the bin owners (threads 0-127, one bin
+// at once, each into its own entries / pool, and after a workgroup barrier the bin owners (threads 0-127, one bin
 // each) add the four areas in batch order -- the same additions in the same order, so the same bits.  One launch holds
 // both forms; the group's count, known on the device only, picks one (descriptor_kernel, team_below).
-struct alignas(16) DescTeamWaveLds {
-    float pool[1024];                          // as DescRowLds::pool
-    uint2 mask[128];
-    unsigned mbase[128];
-};
 struct alignas(16) DescTeamLds {
-    DescTeamWaveLds w[4];
+    DescPool w[4];
     float V[128];
     int Q[128];
     int row_start[2 * SIFT_DESC_MAXRAD + 4];
@@ -360,17 +532,19 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
                                                 int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
                                                 int host_capacity, DescTeamLds &T, double *fold) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    DescTeamWaveLds &L = T.w[wave];
+    DescPool &P = T.w[wave];
     siftmath::load_atan_fold(fold);
-    L.mask[lane] = make_uint2(0u, 0u); L.mask[lane + 64] = make_uint2(0u, 0u);
-    if (lane < 4) L.pool[896 + lane] = 0.0f;
+    desc_pool_init(P, lane);
     __syncthreads();
+    const DescRoute rt = desc_route_of(P, lane);
 
     for (int i = start + blockIdx.x; i < end; i += gridDim.x) {      // workgroup uniform
-        const float4 kq = okp[i];        // (x, y, sigma*oct, angle)
-        const int aux = oaux[i];         // detection scale | octave << 8
-        const int scale = aux & 0xff, oct = aux >> 8;
-        const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
+        float4 kq = okp[i];              // (x, y, sigma*oct, angle)
+        kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
+        kq.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.y)));
+        kq.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.z)));
+        kq.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.w)));
+        const int aux = __builtin_amdgcn_readfirstlane(oaux[i]);         // detection scale | octave << 8
         KpRecord *rec = records + i;
         KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
         if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
@@ -378,19 +552,15 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
             if (wave == 0) store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(T.V));
             continue;
         }
-        const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
-        const float foct = (float)octsize;
-        const float row = kq.y / foct, col = kq.x / foct, angle = kq.w;
-        const int irow = (int)(row + 0.5f), icol = (int)(col + 0.5f);
-        float sine, cosine;
-        siftmath::sincosf_(angle, &sine, &cosine);
-        const float spacing = kq.z / foct * 3.0f;
-        const int R = (int)((1.414f * spacing * 2.5f) + 0.5f);
-        const float drow = row - (float)irow, dcol = col - (float)icol;
+        DescWindow w;
+        int R;
+        desc_window(tab, kq, aux, w, R);
+        const int W = w.W, H = w.H, irow = w.irow, icol = w.icol;
+        const float sine = w.sine, cosine = w.cosine, spacing = w.spacing, drow = w.drow, dcol = w.dcol;
         const int S = 2 * R + 1;
         if (R > SIFT_DESC_MAXRAD) __builtin_trap();   // the host launches descriptor_stream_kernel for such plans
 
-        // ---- 1a. thresholds (every wave for itself: 64 candidates in one ballot), as in descriptor_kernel
+        // ---- 1a. thresholds (every wave for itself: 64 candidates in one ballot), as in descriptor_waves
         auto g = [&](float u) { return u / spacing + 1.5f; };
         float t_hi = 0.0f, t_lo = 0.0f;
         bool thr_ok = spacing > 1e-30f && spacing < 1e30f;
@@ -404,6 +574,7 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
         }
         auto below_hi = [&](float u) { return thr_ok ? (u < t_hi) : (g(u) < 4.0f); };
         auto above_lo = [&](float u) { return thr_ok ? (u > t_lo) : (g(u) > -1.0f); };
+        w.fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;
 
         // ---- 1b. row intervals: thread t owns window row t (S <= 255)
         {
@@ -449,94 +620,44 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
         const int total = T.row_start[S];
 
         // ---- 2 + 3. four batches of 64 ranks at a time, one per wave
-        const float rspacing = 1.0f / spacing;
-        const bool fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;
-        const bool interior = irow - R >= 1 && irow + R <= H - 2 && icol - R >= 1 && icol + R <= W - 2;
-        float4 *pool4 = reinterpret_cast<float4 *>(L.pool);
         float acc = 0.0f;                // bin tid (threads 0-127)
         int rcur = 0;
         for (int t0 = 0; t0 < total; t0 += 256) {                     // workgroup uniform
             const int s = t0 + 64 * wave + lane;
             if (t0 + 64 * wave < total) {                             // wave uniform: this wave has a batch
-                int cbin[8];
+                unsigned tgs[4], tgt[8];
                 float cval[8];
-#pragma unroll
-                for (int n8 = 0; n8 < 8; n8++) { cbin[n8] = -1; cval[n8] = 0.0f; }
-                if (s < total) {
-                    while (s >= T.row_start[rcur + 1]) rcur++;
-                    const int ii = rcur - R, jj = (int)T.row_jlo[rcur] + (s - T.row_start[rcur]);
-                    const float ur = (cosine * (float)ii - sine * (float)jj) - drow, uc = (sine * (float)ii + cosine * (float)jj) - dcol;
-                    const float rx = (fast_div ? siftmath::div_by_reciprocal(ur, spacing, rspacing) : ur / spacing) + 1.5f;
-                    const float cx = (fast_div ? siftmath::div_by_reciprocal(uc, spacing, rspacing) : uc / spacing) + 1.5f;
-                    if (interior) descriptor_sample<true>(I, W, H, icol + jj, irow + ii, rx, cx, angle, fold, cbin, cval);
-                    else descriptor_sample<false>(I, W, H, icol + jj, irow + ii, rx, cx, angle, fold, cbin, cval);
-                }
-                // 3a. contributor masks of this wave's batch
                 {
-                    const unsigned bit = 1u << (lane & 31);
-                    unsigned *mw = reinterpret_cast<unsigned *>(L.mask) + (lane >> 5);
-#pragma unroll
-                    for (int n8 = 0; n8 < 8; n8++)
-                        if (cbin[n8] >= 0) atomicOr(mw + 2 * cbin[n8], bit);
+                    const int sc = min(s, total - 1);
+                    while (sc >= T.row_start[rcur + 1]) rcur++;
+                    const int ii = rcur - R, jj = (int)T.row_jlo[rcur] + (sc - T.row_start[rcur]);
+                    DescSample q;
+                    if (w.interior) { desc_fetch<true>(w, ii, jj, q); desc_eval<true>(w, q, s < total, fold, rt, tgs, tgt, cval); }
+                    else { desc_fetch<false>(w, ii, jj, q); desc_eval<false>(w, q, s < total, fold, rt, tgs, tgt, cval); }
                 }
-                __builtin_amdgcn_wave_barrier();
-                // 3b. segments of this wave's pool
-                const uint2 ia = L.mask[lane], ib = L.mask[lane + 64];
-                const int cnta = __popc(ia.x) + __popc(ia.y), cntb = __popc(ib.x) + __popc(ib.y);
-                const int pa = (cnta + 3) & ~3, pb = (cntb + 3) & ~3;
-                const int base_a = wave_prefix_incl(pa + pb) - (pa + pb);
-                const int base_b = base_a + pa;
-                L.mbase[lane] = (unsigned)base_a;
-                L.mbase[lane + 64] = (unsigned)base_b;
-                if (cnta) pool4[(base_a + pa - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cntb) pool4[(base_b + pb - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                __builtin_amdgcn_wave_barrier();
-                // 3c. values to their ranks (branch free, see descriptor_kernel)
-                uint2 mk[8];
-                unsigned mb[8];
-#pragma unroll
-                for (int n8 = 0; n8 < 8; n8++) {
-                    const int b = max(cbin[n8], 0);
-                    mk[n8] = L.mask[b];
-                    mb[n8] = L.mbase[b];
-                }
-#pragma unroll
-                for (int n8 = 0; n8 < 8; n8++) {
-                    const int pos = mb[n8] + __builtin_amdgcn_mbcnt_hi(mk[n8].y, __builtin_amdgcn_mbcnt_lo(mk[n8].x, 0u));
-                    L.pool[(cbin[n8] >= 0) ? pos : 960 + lane] = cval[n8];
-                }
+                int base_a, pa, pb;
+                desc_route(P, rt, tgs, tgt, cval, lane, base_a, pa, pb);
+                desc_route_reset(P, lane);           // (the owners below read the published entries, not S)
             }
             __syncthreads();
             // 3d. owners: bin tid, the four areas in batch order (an area without a batch this round has empty masks)
             if (tid < 128) {
-                uint2 m[4];
-                unsigned mb[4];
+                uint4 e[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { m[q] = T.w[q].mask[tid]; mb[q] = T.w[q].mbase[tid]; }
-                int n4[4];
-                float4 v[4];
+                for (int q = 0; q < 4; q++) e[q] = *reinterpret_cast<const uint4 *>(&T.w[q].ent[tid]);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    n4[q] = (__popc(m[q].x) + __popc(m[q].y) + 3) >> 2;
-                    v[q] = reinterpret_cast<const float4 *>(T.w[q].pool)[n4[q] ? (mb[q] >> 2) : 224];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (n4[q]) {
-                        float4 cur = v[q];
-                        for (int g4 = 0; g4 < n4[q]; g4++) {
-                            const float4 c4 = cur;
-                            if (g4 + 1 < n4[q]) cur = reinterpret_cast<const float4 *>(T.w[q].pool)[(mb[q] >> 2) + g4 + 1];
-                            acc = acc + c4.x; acc = acc + c4.y; acc = acc + c4.z; acc = acc + c4.w;
-                        }
-                        T.w[q].mask[tid] = make_uint2(0u, 0u);
+                    const int n4 = (__popc(e[q].x) + __popc(e[q].y) + 3) >> 2;
+                    if (n4) {
+                        acc = desc_sum_segment(reinterpret_cast<const float4 *>(T.w[q].pool), (int)((e[q].z - desc_lds_addr(&T.w[q].pool[0])) >> 4), n4, acc);
+                        *reinterpret_cast<uint2 *>(&T.w[q].ent[tid]) = make_uint2(0u, 0u);     // an area may have no batch next round
                     }
                 }
             }
             __syncthreads();
         }
 
-        // ---- 4. normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160), as in descriptor_kernel
+        // ---- 4. normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160), as in descriptor_waves
         auto sum_squares = [&]() {
             float t = 0.0f;
 #pragma unroll 1

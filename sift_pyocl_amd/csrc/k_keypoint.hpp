@@ -70,7 +70,7 @@ struct Counters {
     int n_out;                          // oriented keypoints so far (index into the record list)
     int overflow;                       // set when a list hit its capacity
     int n_kp;                           // refined keypoints so far, all octaves
-    int pad;
+    int tail_timeout;                   // octave_tail_kernel: a workgroup stopped waiting for the octave above (k_tail.hpp)
     int grp_kp_start[SIFT_GROUPS + 1];  // refined-list start of each group
     int grp_out_start[SIFT_GROUPS + 1]; // record-list range of each group, closed by mark_group_kernel
     int grp_out_end[SIFT_GROUPS + 1];
@@ -98,7 +98,7 @@ __global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_c
 
 __global__ void begin_image_kernel(Counters *c) {
     const int t = threadIdx.x;
-    if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; c->mm[0] = 0xffffffffu; c->mm[1] = 0u; }
+    if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; c->tail_timeout = 0; c->mm[0] = 0xffffffffu; c->mm[1] = 0u; }
     if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; c->desc_next[t] = 0; }
     if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
     if (t < 8) c->tail_ready[t] = 0;

@@ -18,6 +18,7 @@
 namespace siftk {
 
 #define SIFT_TAIL_MAX_OCT 6          // octaves one launch can walk
+#define SIFT_TAIL_SPIN (1 << 21)     // polls (~0.5 us each) before a workgroup stops waiting for the octave above
 #define SIFT_TAIL_MAX_PIXELS 4096    // largest plane (W * H) taken; both sides also <= 128 and >= 14 (reflection stays in range)
 #define SIFT_TAIL_THREADS 512      // measured on a 512^2 frame (64^2 + 32^2 + 16^2 octaves): 512 threads 55 us, 1024 (128 VGPRs, spills) 62 us, 256 64 us
 #define SIFT_TAIL_EXT_BUF 32
@@ -124,8 +125,13 @@ __device__ __forceinline__ void tail_blur(float *P, float *A, float *T, float *_
     __syncthreads();
 }
 
-// One workgroup per octave, all resident at once (at most SIFT_TAIL_MAX_OCT workgroups on a 256-CU device; workgroups
-// are dispatched in index order, so the one being waited for is always running or done).  Octave k+1 needs only plane 3
+// One workgroup per octave (at most SIFT_TAIL_MAX_OCT of them, checked on the host).  HIP promises nothing about dispatch
+// order or residency: on this device a grid is dealt round-robin over eight XCDs that dispatch independently, so
+// workgroup k may be resident and polling while workgroup k-1 is still queued (e.g. behind the persistent descriptor
+// workgroups of another batch lane).  That is not a deadlock -- at most five polling workgroups can never keep the sixth
+// from being placed -- but the wait is bounded all the same (SIFT_TAIL_SPIN polls, ~1 s): a workgroup that gives up raises
+// bit 1 of Counters::overflow's neighbour `tail_timeout` and leaves, and the host runs the image again with the
+// per-octave launches (plan_wait / siftmi_plan_keypoints).  Octave k+1 needs only plane 3
 // of octave k: workgroup k raises ready[k] as soon as that plane is in HBM -- before its last two blurs, its extrema and
 // its refinement -- and workgroup k+1 starts from there.  The chain through the tail is then the first three blurs of
 // each octave, not the octaves end to end.  Each workgroup has its own candidate list (cand + k * cand_capacity).
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(SIFT_TAIL_THREADS) void octave_tail_kernel(TailArgs
                                                                        int *__restrict__ n_cand, int *__restrict__ ready,
                                                                        float4 *__restrict__ kp,
                                                                        int *__restrict__ kp_aux, int *__restrict__ n_kp, int kp_capacity,
-                                                                       int *__restrict__ overflow) {
+                                                                       int *__restrict__ overflow, int *__restrict__ timed_out) {
     extern __shared__ float4 tail_smem4[];
     float *smem = reinterpret_cast<float *>(tail_smem4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,10 +153,26 @@ __global__ __launch_bounds__(SIFT_TAIL_THREADS) void octave_tail_kernel(TailArgs
     const int W = o.W, H = o.H, PT = tail_pitch(W);
     float *P = smem, *A = P + H * PT, *T = A + H * (PT + 32);
     if (k) {   // plane 3 of the octave above: acquire at device scope (its stores were released by the raise below)
-        if (tid == 0)
-            while (__hip_atomic_load(ready + k - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+        int *gave_up = reinterpret_cast<int *>(smem);
+        if (tid == 0) {
+            int polls = 0, v;
+            // relaxed polls (an acquire per poll costs 2-3x per hop), one acquire fence once the flag is up
+            while ((v = __hip_atomic_load(ready + k - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++polls < SIFT_TAIL_SPIN)
+                __builtin_amdgcn_s_sleep(8);
+            *gave_up = (v <= 0);               // never raised, or the producer itself gave up (-1)
+        }
         __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent scope: drop any stale line before the loads below
+        if (*gave_up) {                        // workgroup uniform
+            if (tid == 0) {
+                __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k + 1 < a.n) __hip_atomic_store(ready + k, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // pass it on at once
+            }
+            return;
+        }
+        // one agent-scope acquire per workgroup (it invalidates this CU's L1; the XCD's L2 was written back by the
+        // producer's release), then the barrier: no thread loads plane 3 before the invalidate, nor overwrites the flag word
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
     }
     // ---- octave hand-off: every second sample of the plane above
     for (int i = tid; i < W * H; i += SIFT_TAIL_THREADS) {

@@ -189,8 +189,9 @@ __device__ __forceinline__ bool f32_rounding_is_safe(double v) {
 
 // exp(x): one-step reduction x = k ln2 + r with a fused two-part ln2 (|r| <= 0.3466, reduction error < 2^-60),
 // Taylor degree 11 by fused Horner (truncation r^12/12! < 2^-47 relative), scaling by an exponent-field add.
-__device__ __forceinline__ float expf_fast(float xf) {
-    if (!(__builtin_fabsf(xf) <= 80.0f)) return expf_(xf);   // result outside the normal binary32 range, or NaN
+// The *_try forms are branch free: they return the candidate and whether it may be used, so that a caller can run
+// several of them in one basic block (their dependent binary64 chains then interleave) and branch once.
+__device__ __forceinline__ float expf_fast_try(float xf, bool &ok) {
     const double x = (double)xf;
     const double kd = __builtin_rint(x * 0x1.71547652b82fep+0);
     double r = __builtin_fma(-kd, 0x1.62e42fee00000p-1, x);
@@ -209,8 +210,14 @@ __device__ __forceinline__ float expf_fast(float xf) {
     p = __builtin_fma(p, r, 1.0);
     // p in [0.70, 1.42], |k| <= 116: adding k to the exponent field is an exact scaling
     const double v = __hiloint2double(__double2hiint(p) + (int)kd * (1 << 20), __double2loint(p));
-    if (!f32_rounding_is_safe(v)) return expf_(xf);
+    // usable: argument inside the guarded range (result in the normal binary32 range, not NaN) and a safe rounding
+    ok = (__builtin_fabsf(xf) <= 80.0f) && f32_rounding_is_safe(v);
     return (float)v;
+}
+__device__ __forceinline__ float expf_fast(float xf) {
+    bool ok;
+    const float v = expf_fast_try(xf, ok);
+    return ok ? v : expf_(xf);
 }
 
 // atan2(y, x) for finite non-zero arguments of comparable size (the gradient components of a window sample):
@@ -218,12 +225,14 @@ __device__ __forceinline__ float expf_fast(float xf) {
 // |num/den - k/8| <= 1/16 + 2^-20 serves), t = (num - c den) / (den + c num) by a Newton reciprocal (two steps from the
 // hardware seed: error < 2^-50), odd Taylor polynomial through t^11 (|t| <= 0.0626: truncation < 2^-51 relative), and
 // the three reflections of atan2f_ folded into one table value (c_atan_fold).  `fold` is the block's LDS copy.
-__device__ __forceinline__ float atan2f_fast(float yf, float xf, const double *fold) {
+__device__ __forceinline__ float atan2f_fast_try(float yf, float xf, const double *fold, bool &ok) {
     const float ay = __builtin_fabsf(yf), ax = __builtin_fabsf(xf);
     const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
-    if (!(ax <= 1e18f && ay <= 1e18f && mn >= 1e-18f)) return atan2f_(yf, xf);   // zero / huge / NaN operands (fmin / fmax drop a NaN), or a sub-normal result
+    // guarded range: no zero / huge / NaN operand (fmin / fmax drop a NaN), no sub-normal result
+    const bool in_range = ax <= 1e18f && ay <= 1e18f && mn >= 1e-18f;
     const bool swap = ay > ax;
-    const int k = (int)(mn * __builtin_amdgcn_rcpf(mx) * 8.0f + 0.5f);        // 0..8
+    int k = (int)(mn * __builtin_amdgcn_rcpf(mx) * 8.0f + 0.5f);               // 0..8 inside the guarded range
+    k = k < 0 ? 0 : (k > 8 ? 8 : k);                                           // (keeps the table index in bounds outside it)
     const double c = (double)((float)k * 0.125f);
     const double num = (double)mn, den = (double)mx;
     const double tn = __builtin_fma(-c, den, num), td = __builtin_fma(c, num, den);
@@ -241,9 +250,14 @@ __device__ __forceinline__ float atan2f_fast(float yf, float xf, const double *f
     const int f = (swap ? 1 : 0) + (__builtin_signbitf(xf) ? 2 : 0);
     const double base = fold[f * 9 + k];
     const double res = (f == 1 || f == 2) ? base - at : base + at;
-    if (!f32_rounding_is_safe(res)) return atan2f_(yf, xf);
+    ok = in_range && f32_rounding_is_safe(res);
     const float out = (float)res;
     return __builtin_signbitf(yf) ? -out : out;
+}
+__device__ __forceinline__ float atan2f_fast(float yf, float xf, const double *fold) {
+    bool ok;
+    const float v = atan2f_fast_try(yf, xf, fold, ok);
+    return ok ? v : atan2f_(yf, xf);
 }
 
 // a / b correctly rounded, given rb = 1.0f / b correctly rounded (Markstein): q0 = RN(a rb) is within 2 ulp of a / b;

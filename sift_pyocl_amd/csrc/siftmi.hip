@@ -37,6 +37,7 @@ namespace {
 
 thread_local std::string g_err;
 
+#define SIFTMI_ETAILRETRY (-100)   // internal: plan_wait -> siftmi_plan_keypoints, never returned through the C ABI
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -503,6 +504,7 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
     a.src = p->plane(first - 1, 3);
     a.src_w = p->ow[(size_t)first - 1];
     a.n = p->n_oct - first;
+    if (a.n < 1 || a.n > SIFT_TAIL_MAX_OCT) return fail(SIFTMI_EINVAL, "octave_tail_kernel walks 1..%d octaves, not %d", SIFT_TAIL_MAX_OCT, a.n);
     for (int k = 0; k < a.n; k++) {
         const int oct = first + k;
         TailOctave &o = a.o[k];
@@ -528,7 +530,7 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
     const int kcap = (int)p->kpsize;
     hipLaunchKernelGGL(octave_tail_kernel, dim3((unsigned)a.n), dim3(SIFT_TAIL_THREADS), lds, st, a, p->par.border_dist,
                        contrast_threshold(p->par), p->par.peak_thresh, (float)p->par.init_sigma, p->tail_cand, p->tail_cand_cap,
-                       p->cnt->n_cand, p->cnt->tail_ready, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, &p->cnt->overflow);
+                       p->cnt->n_cand, p->cnt->tail_ready, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, &p->cnt->overflow, &p->cnt->tail_timeout);
     return SIFTMI_OK;
 }
 
@@ -993,6 +995,12 @@ int enqueue_body(siftmi_plan *p) {
     return SIFTMI_OK;
 }
 
+// wait for everything in flight on the plan's streams, ignoring errors (error paths only)
+static void drain_streams(siftmi_plan *p) {
+    for (hipStream_t s : {p->stream, p->stream2, p->stream3})
+        if (s) (void)hipStreamSynchronize(s);
+}
+
 // Wait for the image enqueued last on this plan; returns its record count (records stay on the device).
 int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     HIPCHK(hipSetDevice(p->device));
@@ -1015,6 +1023,13 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
         p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
+    }
+    if (p->hb->c.tail_timeout || (p->wait_b && p->hb->c2.tail_timeout)) {
+        // a workgroup of octave_tail_kernel stopped waiting for the octave above (k_tail.hpp): this image is incomplete.
+        // From now on the plan walks the small octaves with the per-octave launches; the caller runs the image again.
+        p->opt.tail = 0;
+        drain_streams(p);
+        return fail(SIFTMI_ETAILRETRY, "octave_tail_kernel timed out waiting for the previous octave; tail launches disabled for this plan");
     }
     int64_t n = hc.n_out;
     // the overflow flag may have been raised by either detection stream after the other took its snapshot
@@ -1043,11 +1058,21 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     p->host_out = pinned ? reinterpret_cast<KpRecord *>(out) : nullptr;
     p->host_cap = pinned ? (int)(capacity < 0x7fffffff ? capacity : 0x7fffffff) : 0;
     int rc = plan_enqueue(p, image, image_dtype, image_is_device, true);
-    p->host_out = nullptr; p->host_cap = 0;
-    if (rc) return rc;
     int64_t n = 0;
     int32_t ovf = 0;
-    if ((rc = plan_wait(p, &n, &ovf))) return rc;
+    if (!rc) rc = plan_wait(p, &n, &ovf);
+    if (rc == SIFTMI_ETAILRETRY) {           // once: plan_wait has switched the plan to the per-octave launches
+        rc = plan_enqueue(p, image, image_dtype, image_is_device, true);
+        if (!rc) rc = plan_wait(p, &n, &ovf);
+        if (rc == SIFTMI_ETAILRETRY) rc = SIFTMI_EDEVICE;
+    }
+    p->host_out = nullptr; p->host_cap = 0;
+    if (rc) {
+        // descriptor kernels that were already launched may still be writing to the caller's pinned block: nothing
+        // returns before every stream of the plan has drained (the caller recycles the block on an error)
+        if (pinned) drain_streams(p);
+        return rc;
+    }
     hipStream_t fin = p->fin;
     if (out == nullptr && capacity == 0) {
         // count-only call: the records stay on the device until siftmi_plan_fetch()
@@ -1234,6 +1259,7 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     if (img >= b->batch_size) { b->lane_image[l] = -1; return fail(SIFTMI_EINVAL, "stale frame index %d on lane %zu", img, l); }
     int64_t n = 0; int32_t ovf = 0;
     int rc = plan_wait(p, &n, &ovf);
+    if (rc == SIFTMI_ETAILRETRY) rc = SIFTMI_EDEVICE;     // the frame is gone from the batch's lanes: report, do not retry here
     if (rc) return rc;
     if (ovf && overflow) *overflow = 1;
     if (p->profile) {

@@ -268,10 +268,17 @@ class SiftPlan(object):
             # numpy.empty cost nothing), so the host does not come back to Python between the count and the copy.  If the
             # frame has more keypoints than guessed, the records are still on the device: fetch them into an exact array.
             cap = int(1.5 * self._last_n) + 256
+            output = None
             if cap * 144 <= (8 << 20) and self.pinned_results:
                 # pinned result array from the library's pool: the descriptor kernels write the records straight into
-                # it (SIFTMI_OUT_PINNED), nothing is copied after the last kernel; it is recycled when the caller drops it
-                output = _lib.pinned_empty(cap, self.dtype_kp)
+                # it (SIFTMI_OUT_PINNED), nothing is copied after the last kernel; it is recycled when the caller drops it.
+                # Callers that keep many results alive accumulate page-locked memory: when the pool cannot grow any more
+                # the call falls back to an ordinary array (one copy after the last kernel).
+                try:
+                    output = _lib.pinned_empty(cap, self.dtype_kp)
+                except MemoryError:
+                    output = None
+            if output is not None:
                 rc = L.siftmi_plan_keypoints(self._handle, ptr, code, is_dev, output.ctypes.data, 2, cap, C.byref(n), C.byref(ovf))
                 _lib.check(rc, allow=(_lib.ECAPACITY,))
                 count = n.value
@@ -295,7 +302,10 @@ class SiftPlan(object):
                 if count:
                     _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, count))
             self._last_n = count
-            output = output[:count]
+            if count * 144 <= (16 << 10) and output.nbytes >= (64 << 10) and not exact:
+                output = output[:count].copy()      # a small result does not keep a 64 KiB page-locked block alive
+            else:
+                output = output[:count]
             self.overflow = bool(ovf.value)
             if self.overflow:
                 logger.warning("Keypoint counter overflow: more than %s keypoints, result truncated", self.kpsize)

@@ -27,7 +27,7 @@ def _worker(rank, world, port, n_items, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items", [5, 2])
+@pytest.mark.parametrize("n_items", [5, 2, 1])     # 1: rank 1 owns no frame
 def test_gather_records_world2(n_items):
     import torch.multiprocessing as mp
     from oracle import pyoracle
@@ -36,6 +36,48 @@ def test_gather_records_world2(n_items):
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + n_items
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expected = [pyoracle.keypoints(smooth_noise((96 + 8 * i, 120), seed=100 + i)).tobytes() for i in range(n_items)]
+    assert results[0] == expected and results[1] == expected
+
+
+def _worker_device_form(rank, world, port, n_items, q):
+    """gather_records_device + split_gathered (the RCCL path's code, here on CPU tensors over gloo), incl. an empty shard"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SIFTMI_STANDALONE"] = "1"
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle
+    from sift_pyocl_amd.batch import gather_records_device, shard_indices, split_gathered
+    from util import smooth_noise
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_items, rank, world)
+    local = [pyoracle.keypoints(smooth_noise((96 + 8 * i, 120), seed=100 + i)) for i in mine]
+    counts = [len(k) for k in local]
+    raw = b"".join(np.ascontiguousarray(k).tobytes() for k in local)
+    records = torch.frombuffer(bytearray(raw), dtype=torch.uint8) if raw else torch.empty(0, dtype=torch.uint8)
+    all_counts, gathered = gather_records_device(counts, records, n_items, rank, world)
+    allk = split_gathered(all_counts, gathered, n_items, world)
+    q.put((rank, [k.tobytes() for k in allk]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [3, 1])
+def test_gather_records_device_form_world2(n_items):
+    import torch.multiprocessing as mp
+    from oracle import pyoracle
+    from util import smooth_noise
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + n_items
+    procs = [ctx.Process(target=_worker_device_form, args=(r, 2, port, n_items, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=240) for _ in range(2))

@@ -84,17 +84,24 @@ for k in keys[:40]:
 # 16-byte loads read exactly 4 B/pixel and are reported at 1/2), writes x1 (blur / shrink stores are exact)
 import json
 cal = [v for (n, g), vs in fetch.items() if n == "minmax_kernel" for v in vs]
-# full-resolution launches only (the blur launches that write a whole octave-0 plane), as bench.py's roofline object
-avg_w = {k: sum(v) / len(v) for k, v in write.items() if k[0].startswith("blur_") and v}
-full = max(avg_w.values()) if avg_w else 0.0
-full_keys = {k for k, w in avg_w.items() if w >= 0.99 * full}
-sel = lambda n, g: (n, g) in full_keys
+# full-resolution launches only: the marching instances on their LARGEST grid (octave 0), exactly the launches bench.py's
+# roofline object times -- selected by kernel name and grid, never by byte counts (the launch that also writes the next
+# octave's plane 0 stores 1.25 planes and would otherwise be the only one "near the maximum")
+pmc_grid = {}
+for (n, g) in set(fetch) | set(write):
+    if is_full(n):
+        pmc_grid[n] = max(pmc_grid.get(n, 0), int(g))
+sel = lambda n, g: is_full(n) and int(g) == pmc_grid.get(n, -1)
+images_f = sum(len(v) for (n, g), v in fetch.items() if n == "minmax_kernel")
+images_w = sum(len(v) for (n, g), v in write.items() if n == "minmax_kernel")
 nb = sum(len(v) for (n, g), v in fetch.items() if sel(n, g))
 fb = sum(sum(v) for (n, g), v in fetch.items() if sel(n, g)) * 1024.0
 wb = sum(sum(v) for (n, g), v in write.items() if sel(n, g)) * 1024.0
 nw = sum(len(v) for (n, g), v in write.items() if sel(n, g))
 if nb and nw:
     out = {"kernel_family": "blur, full-resolution (octave 0) launches", "launches_fetch_pass": nb, "launches_write_pass": nw,
+           "images_fetch_pass": images_f, "images_write_pass": images_w, "launches_per_image": 6,
+           "complete": bool(nb == 6 * images_f and nw == 6 * images_w),
            "fetch_size_bytes_per_launch_reported": fb / nb, "read_correction": 2.0,
            "write_size_bytes_per_launch": wb / nw,
            "traffic_bytes_per_launch": 2.0 * fb / nb + wb / nw,

@@ -10,6 +10,14 @@
 // Tie-breaking parity: the reference scans j ascending with strict '<', so the earliest index of the
 // minimum wins and dist2 is the second smallest value of the multiset.  Both properties survive the
 // partition merge when partitions are folded in ascending order with '<' for "later beats earlier".
+//
+// Inside a partition the two smallest are kept as packed keys (distance << 16 | index in the partition): the 32
+// accumulations of a pair are v_sad_hi_u8 (adds the byte SAD to the UPPER half), started from the index, so the key
+// costs nothing; then key2 = med3(key1, key2, key) (the second smallest of the three, key1 <= key2 being invariant)
+// and key1 = min(key1, key): two instructions per pair instead of the compare / select chain (six).  An equal
+// distance at a later index is a larger key: it never displaces the first and it does become the second -- exactly
+// the reference's `if (d < d1) ... else if (d < d2)`.  (Round 3: the kernel issues one VALU instruction per ~3.6
+// cycles per SIMD whatever it is, so 100k x 100k is 10^10 pairs x (32 + bookkeeping) / 64 lanes of pure issue.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,8 +27,12 @@ namespace siftk {
 #define SIFT_MATCH_QPT 2
 #define SIFT_MATCH_TILE 64
 #define SIFT_MATCH_NONE 0x7fffffff
+#define SIFT_MATCH_MAX_PART 65472        // list elements per partition: the index shares a key with the distance (16 bits)
 
 struct MatchPartial { int d1, best, d2, pad; };
+
+// median of three unsigned values, written in the form the backend selects v_med3_u32 for
+__device__ __forceinline__ uint32_t match_umed3(uint32_t x, uint32_t y, uint32_t z) { return max(min(x, y), min(max(x, y), z)); }
 
 // FLAGS (ROI-masked / mutual variants, matching_cpu.cl:136-199): qflag[i] bit 0 = every distance of this query is
 // forced to 0; lflag[j] = 1: distance to this list element is forced to 0 (the literal `matching_valid` behaviour for
@@ -37,12 +49,12 @@ __global__ __launch_bounds__(256) void match_partial_kernel(const uint8_t *__res
     const int j_begin = blockIdx.y * part_len, j_end = min(j_begin + part_len, n2);
     uint32_t q[SIFT_MATCH_QPT][32];
     int qi[SIFT_MATCH_QPT];
-    int d1[SIFT_MATCH_QPT], d2[SIFT_MATCH_QPT], best[SIFT_MATCH_QPT];
+    uint32_t key1[SIFT_MATCH_QPT], key2[SIFT_MATCH_QPT];      // (distance << 16 | index - j_begin) of the smallest / second smallest
     bool qzero[SIFT_MATCH_QPT];
 #pragma unroll
     for (int u = 0; u < SIFT_MATCH_QPT; u++) {
         qi[u] = (blockIdx.x * SIFT_MATCH_QPT + u) * 256 + tid;
-        d1[u] = SIFT_MATCH_NONE; d2[u] = SIFT_MATCH_NONE; best[u] = 0;
+        key1[u] = SIFT_MATCH_NONE; key2[u] = SIFT_MATCH_NONE;
         const int src = min(qi[u], n1 - 1);
         qzero[u] = FLAGS && (qflag[src] & 1);
         const uint4 *p = reinterpret_cast<const uint4 *>(kp1 + (size_t)src * 144 + 16);
@@ -73,36 +85,42 @@ __global__ __launch_bounds__(256) void match_partial_kernel(const uint8_t *__res
         }
         const int jn = min(SIFT_MATCH_TILE, j_end - j0);
         const uint4 *tb = tile[buf];
+        const uint32_t jl0 = (uint32_t)(j0 - j_begin);
+#pragma unroll 4
         for (int j = 0; j < jn; j++) {
             int lf = 0;
             if (FLAGS) { lf = tflag[buf][j]; if (lf == 2) continue; }      // wave-uniform
-            uint32_t dist[SIFT_MATCH_QPT];
+            uint32_t key[SIFT_MATCH_QPT];
 #pragma unroll
-            for (int u = 0; u < SIFT_MATCH_QPT; u++) dist[u] = 0;
+            for (int u = 0; u < SIFT_MATCH_QPT; u++) key[u] = jl0 + (uint32_t)j;
 #pragma unroll
             for (int w = 0; w < 8; w++) {
                 const uint4 v = tb[j * 8 + w];
 #pragma unroll
                 for (int u = 0; u < SIFT_MATCH_QPT; u++) {
-                    dist[u] = __builtin_amdgcn_sad_u8(q[u][4 * w], v.x, dist[u]);
-                    dist[u] = __builtin_amdgcn_sad_u8(q[u][4 * w + 1], v.y, dist[u]);
-                    dist[u] = __builtin_amdgcn_sad_u8(q[u][4 * w + 2], v.z, dist[u]);
-                    dist[u] = __builtin_amdgcn_sad_u8(q[u][4 * w + 3], v.w, dist[u]);
+                    key[u] = __builtin_amdgcn_sad_hi_u8(q[u][4 * w], v.x, key[u]);
+                    key[u] = __builtin_amdgcn_sad_hi_u8(q[u][4 * w + 1], v.y, key[u]);
+                    key[u] = __builtin_amdgcn_sad_hi_u8(q[u][4 * w + 2], v.z, key[u]);
+                    key[u] = __builtin_amdgcn_sad_hi_u8(q[u][4 * w + 3], v.w, key[u]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < SIFT_MATCH_QPT; u++) {
-                const int d = (FLAGS && (lf == 1 || qzero[u])) ? 0 : (int)dist[u];
-                // strict '<' and ascending j: the earliest index wins ties (matching_cpu.cl:92-100)
-                if (d < d1[u]) { d2[u] = d1[u]; d1[u] = d; best[u] = j0 + j; }
-                else if (d < d2[u]) d2[u] = d;
+                if (FLAGS && (lf == 1 || qzero[u])) key[u] = jl0 + (uint32_t)j;           // distance forced to 0
+                // ascending index inside equal distances: the earliest index wins ties (matching_cpu.cl:92-100)
+                key2[u] = match_umed3(key1[u], key2[u], key[u]);
+                key1[u] = min(key1[u], key[u]);
             }
         }
     }
 #pragma unroll
     for (int u = 0; u < SIFT_MATCH_QPT; u++)
         if (qi[u] < n1) {
-            MatchPartial r; r.d1 = d1[u]; r.best = best[u]; r.d2 = d2[u]; r.pad = 0;
+            MatchPartial r;
+            r.d1 = (key1[u] >> 16) == 0x7fffu ? SIFT_MATCH_NONE : (int)(key1[u] >> 16);
+            r.best = (key1[u] >> 16) == 0x7fffu ? 0 : j_begin + (int)(key1[u] & 0xffffu);
+            r.d2 = (key2[u] >> 16) == 0x7fffu ? SIFT_MATCH_NONE : (int)(key2[u] >> 16);
+            r.pad = 0;
             partial[(size_t)blockIdx.y * n1 + qi[u]] = r;
         }
 }

@@ -1611,6 +1611,8 @@ int match_direction(siftmi_matcher *m, const uint8_t *dq, int64_t nq, const uint
     int nparts = (2048 + qblocks - 1) / qblocks;
     const int max_parts = (int)((nl + 4 * SIFT_MATCH_TILE - 1) / (4 * SIFT_MATCH_TILE));
     if (nparts > max_parts) nparts = max_parts;
+    const int min_parts = (int)((nl + SIFT_MATCH_MAX_PART - 1) / SIFT_MATCH_MAX_PART);     // 16-bit index inside a partition
+    if (nparts < min_parts) nparts = min_parts;
     if (nparts < 1) nparts = 1;
     int part_len = (int)((nl + nparts - 1) / nparts);
     part_len = (part_len + SIFT_MATCH_TILE - 1) / SIFT_MATCH_TILE * SIFT_MATCH_TILE;

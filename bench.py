@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="image side (default: the BASELINE config: 4096 for c2, 2048 for c4)")
     ap.add_argument("--octaves", type=int, default=-1, help="0 = every octave (reference default); default 3 for c2, all for c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the 200-step steady-state measurement after the timed region")
     ap.add_argument("--no-pipelined", "--no-extras", dest="no_extras", action="store_true",
                     help="skip the extra measurements (BatchPlan, host-to-host, MatchPlan)")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default nccl = RCCL; gloo only with --share-gpu)")
@@ -334,11 +335,23 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         total_kp = n_kp
+        # beside `value`: the same step over a window long enough for the clocks to settle (the first dozen calls after an
+        # idle period run 3-5 % slower; the driver's 20-step window is mostly that ramp) -- reported, never `value`
+        steady = None
+        if world == 1 and not args.no_steady:
+            ns = 200
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(ns):
+                plan.keypoints(dev_images[i % n_img])
+            torch.cuda.synchronize()
+            steady = {"ms_per_step_steady": round(1e3 * (time.perf_counter() - t1) / ns, 4), "steps": ns,
+                      "note": "same call, %d further steps right after the timed region" % ns}
         units = world * K * size * size / 1e6
         workload = ("SiftPlan %dx%d fp32 uniform white noise (numpy default_rng(seed).random), %d octaves x 3 scales, input "
                     "resident in HBM, records returned to host" % (size, size, n_oct))
         result.update(scaling="weak", images_per_step=world, kp_per_img=n_kp / max(K, 1), n_oct=n_oct)
-        kt = dict(b0_ms=b0_ms, b0_px=b0_px, b0_launches=b0_launches, tot_ms=tot_ms)
+        kt = dict(b0_ms=b0_ms, b0_px=b0_px, b0_launches=b0_launches, tot_ms=tot_ms, steady=steady)
 
     if distributed:
         el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
@@ -405,6 +418,8 @@ def main():
                                         "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
                                         "kernel_ms_per_image": round(kt["tot_ms"] / max(K, 1), 4),
                                         "bytes_alg_per_image": bytes_alg(size, size, result["n_oct"], result["kp_per_img"])}
+        if kt is not None and kt.get("steady"):
+            out["steady"] = kt["steady"]
         out.update(extra)
         if not args.no_cpu_baseline and world == 1 and not c4:
             out["cpu_baseline"] = cpu_baseline(size, result["n_oct"])

@@ -261,14 +261,21 @@ __device__ __forceinline__ void desc_route(DescPool &P, const DescRoute &rt, con
     __builtin_amdgcn_wave_barrier();
     // ---- 3c. every value to segment start + 4 * rank among the contributors of its bin (mbcnt: set bits of the mask
     //          below this lane); the eight 16-byte reads are in flight together
-    uint4 e[8];
-    e[0] = desc_entry<16 * SIFT_DESC_C0>(tgt[0]); e[1] = desc_entry<16 * SIFT_DESC_C0>(tgt[1]);
-    e[2] = desc_entry<16 * SIFT_DESC_C1>(tgt[2]); e[3] = desc_entry<16 * SIFT_DESC_C1>(tgt[3]);
-    e[4] = desc_entry<16 * SIFT_DESC_C2>(tgt[4]); e[5] = desc_entry<16 * SIFT_DESC_C2>(tgt[5]);
-    e[6] = desc_entry<16 * SIFT_DESC_C3>(tgt[6]); e[7] = desc_entry<16 * SIFT_DESC_C3>(tgt[7]);
-#pragma unroll
-    for (int n8 = 0; n8 < 8; n8++)
-        *reinterpret_cast<desc_lds_f32 *>(e[n8].z + 4u * __builtin_amdgcn_mbcnt_hi(e[n8].y, __builtin_amdgcn_mbcnt_lo(e[n8].x, 0u))) = cval[n8];
+    // (two rounds of four: eight 12-byte entries at once cost 24 registers at the kernel's register peak)
+    auto place = [&](const uint4 &en, float v) {
+        *reinterpret_cast<desc_lds_f32 *>(en.z + 4u * __builtin_amdgcn_mbcnt_hi(en.y, __builtin_amdgcn_mbcnt_lo(en.x, 0u))) = v;
+    };
+    {
+        const uint4 e0 = desc_entry<16 * SIFT_DESC_C0>(tgt[0]), e1 = desc_entry<16 * SIFT_DESC_C0>(tgt[1]);
+        const uint4 e2 = desc_entry<16 * SIFT_DESC_C1>(tgt[2]), e3 = desc_entry<16 * SIFT_DESC_C1>(tgt[3]);
+        place(e0, cval[0]); place(e1, cval[1]); place(e2, cval[2]); place(e3, cval[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const uint4 e4 = desc_entry<16 * SIFT_DESC_C2>(tgt[4]), e5 = desc_entry<16 * SIFT_DESC_C2>(tgt[5]);
+        const uint4 e6 = desc_entry<16 * SIFT_DESC_C3>(tgt[6]), e7 = desc_entry<16 * SIFT_DESC_C3>(tgt[7]);
+        place(e4, cval[4]); place(e5, cval[5]); place(e6, cval[6]); place(e7, cval[7]);
+    }
     __builtin_amdgcn_wave_barrier();
 }
 

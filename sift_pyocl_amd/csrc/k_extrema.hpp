@@ -226,8 +226,10 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
     if (REFINE) refine_parked();
 }
 
+// (the fused-refinement form is the one of small planes, a latency chain of few workgroups: it takes the registers it
+// needs -- at the five-wave budget it spilled four to scratch)
 template <bool REFINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REFINE ? 4 : SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
                                                       float edth, float4 *__restrict__ cand,
                                                       int *__restrict__ counter, int capacity, RefineArgs ra) {
     __shared__ ExtWaveLds lds_all[4];
@@ -271,7 +273,11 @@ __device__ __forceinline__ void refine_candidates(const BlurPlanes &b, int W, in
         int r = (int)k.y, c = (int)k.z;
         const int scale = (int)k.w;
         if (r == -1) continue;
-        const float *Pa = b.p[scale - 1], *Pb = b.p[scale], *Pc = b.p[scale + 1], *Pd = b.p[scale + 2];
+        // (selects, not b.p[scale + k]: a BlurPlanes built at run time -- the tail kernel's -- indexed by a per-lane value
+        // would have to live in scratch memory)
+        const float *Pa = b.p[0], *Pb = b.p[1], *Pc = b.p[2], *Pd = b.p[3];
+        if (scale == 2) { Pa = b.p[1]; Pb = b.p[2]; Pc = b.p[3]; Pd = b.p[4]; }
+        else if (scale == 3) { Pa = b.p[2]; Pb = b.p[3]; Pc = b.p[4]; Pd = b.p[5]; }
         // P = DoG[scale-1] = Pa-Pb, D = DoG[scale] = Pb-Pc, N = DoG[scale+1] = Pc-Pd
         int newr = r, newc = c, moves = 5;
         bool again = true;

@@ -416,7 +416,7 @@ struct DescWaveLds {
 };
 
 // 5 waves per SIMD (96 VGPRs, 20 bytes of scratch): +12 % on keypoint-dense frames against the natural 116 VGPRs / 4 waves
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void descriptor_stream_kernel(OctaveTable tab, const float4 *__restrict__ okp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void descriptor_stream_kernel(OctaveTable tab, const float4 *__restrict__ okp,
                                                          const int *__restrict__ oaux, const Counters *cnt, int group,
                                                          int range_start, int range_end,  // used when cnt == nullptr
                                                          int out_capacity, KpRecord *__restrict__ records,

@@ -135,7 +135,9 @@ __device__ __forceinline__ void tail_blur(float *P, float *A, float *T, float *_
 // of octave k: workgroup k raises ready[k] as soon as that plane is in HBM -- before its last two blurs, its extrema and
 // its refinement -- and workgroup k+1 starts from there.  The chain through the tail is then the first three blurs of
 // each octave, not the octaves end to end.  Each workgroup has its own candidate list (cand + k * cand_capacity).
-__global__ __launch_bounds__(SIFT_TAIL_THREADS) void octave_tail_kernel(TailArgs a, int border, double contrast, float peak_thresh,
+// (one 512-thread workgroup per CU: two waves per SIMD whatever the register count -- the whole 256-register budget is
+// there to be used; under the default occupancy heuristic the kernel kept 167 and spilled 56 bytes per lane)
+__global__ __launch_bounds__(SIFT_TAIL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void octave_tail_kernel(TailArgs a, int border, double contrast, float peak_thresh,
                                                                        float init_sigma, float4 *__restrict__ cand_all, int cand_capacity,
                                                                        int *__restrict__ n_cand, int *__restrict__ ready,
                                                                        float4 *__restrict__ kp,

@@ -252,8 +252,10 @@ void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *ou
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     switch (blur_tile_class(opt, W, H)) {
+#ifdef SIFT_DEV_VARIANTS       // the larger tiles lost on every plane that reaches this kernel: development builds only
         case 1: launch_blur_geom<N, NORM, DT, 128, 64, 8>(st, in, out, W, H, ta, mm, half); break;
         case 2: launch_blur_geom<N, NORM, DT, 64, 32, 8>(st, in, out, W, H, ta, mm, half); break;
+#endif
         default: launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm, half); break;
     }
 }
@@ -312,11 +314,13 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
 // returns whether `half` (the fused octave hand-off) was written: the one-block marching form does not do it
 template <int N, bool NORM, int DT = 0>
 bool launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
+#ifdef SIFT_DEV_VARIANTS       // the one-block marching form (options "team" = 0, "march_nt"): development builds only
     if (!opt.team) {
         if (opt.march_nt == 64) launch_march_nt<N, NORM, 64, DT>(opt, st, in, out, W, H, taps, mm);
         else launch_march_nt<N, NORM, 128, DT>(opt, st, in, out, W, H, taps, mm);
         return false;
     }
+#endif
     constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
     launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024, half);
     return half != nullptr;
@@ -331,6 +335,14 @@ template <bool NORM>
 int launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm, float *half = nullptr) {
     bool symmetric = true;
     for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
+    if constexpr (NORM) {
+        // The normalising form exists for the default initial kernel only (15 taps, init_sigma = 1.6); any other
+        // InitSigma sends its ONE initial blur through the generic two-pass path (return 0).
+        if (t.n != 15) return 0;
+        if (march_plane(W, H) && symmetric && opt.march) return launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
+        launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half);
+        return half ? 2 : 1;
+    } else {
     if (march_plane(W, H) && symmetric && opt.march) {
         switch (t.n) {
             case 11: return launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
@@ -348,6 +360,7 @@ int launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float
         case 21: launch_blur_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
         case 27: launch_blur_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
         default: return 0;
+    }
     }
 }
 

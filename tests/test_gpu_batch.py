@@ -74,3 +74,28 @@ def test_batch_of_blank_frames(siftlib, lanes):
     # and a mixed batch still delivers the non-empty frame
     mixed = bp.keypoints_batch([blank, white_noise(shape, seed=3)])
     assert len(mixed[0]) == 0 and len(mixed[1]) > 10
+
+
+def test_c4_shape_16_lanes_against_the_oracle(siftlib, oracle):
+    """BASELINE.json configs[3] as bench.py --config c4 runs it on one rank: the default BatchPlan for 2048 x 2048 frames
+    (16 parked lanes), 16 device-resident frames.  A sample of the frames is compared with the ORACLE (not with SiftPlan),
+    and the device-side hand-back (keypoints_batch_device -> split_gathered, the single-rank form of the exchange)
+    must deliver the same records as keypoints_batch."""
+    import torch
+    import sift_pyocl_amd as sp
+    from sift_pyocl_amd.batch import split_gathered
+    shape = (2048, 2048)
+    frames = [white_noise(shape, seed=1000 + i) if i % 4 else smooth_noise(shape, seed=1000 + i, sigma=2.0) for i in range(16)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    bp = sp.BatchPlan(shape=shape, dtype=np.float32)            # default lanes: what the bench uses
+    assert bp.lanes == 16
+    got = bp.keypoints_batch(dev)
+    assert len(got) == 16
+    for i in (0, 5, 10, 15):
+        assert_same_keypoints(got[i], oracle.keypoints(frames[i]), "c4 frame %d, 16 lanes" % i)
+    counts, records = bp.keypoints_batch_device(dev)
+    assert counts == [len(g) for g in got]
+    assert records.numel() == sum(counts) * 144
+    back = split_gathered([counts], records.view(1, -1), 16, 1)
+    for i in range(16):
+        assert_same_keypoints(back[i], got[i], "device hand-back, frame %d" % i)

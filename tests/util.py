@@ -65,7 +65,7 @@ def ulp_diff(a, b):
     return np.abs(a - b)
 
 
-def compare_keypoints_libm(a, b, what="", max_bad_rows=0.002, angle_abs=0.05, desc_lsb=10, scale_ulp=2):
+def compare_keypoints_libm(a, b, what="", max_bad_rows=0.002, angle_abs=0.02, desc_lsb=6, scale_ulp=2):
     """Comparison against the glibc-backed native build of the reference kernels (oracle/_ref/libsiftclref.so).
 
     OpenCL leaves the last bits of exp / atan2 / pow to the implementation; the oracle's siftmath is correctly rounded
@@ -73,8 +73,9 @@ def compare_keypoints_libm(a, b, what="", max_bad_rows=0.002, angle_abs=0.05, de
     (tests/test_oracle_vs_ref.py::test_glibc_build_tolerance, 60 k keypoints): count, x and y identical; scale within
     2 ulp; angle and descriptor identical in > 99.9 % of the rows.  In the remaining rows a 1-ulp atan2 difference
     moved one window sample across an orientation-bin edge (orientation_cpu.cl:88), which shifts the interpolated
-    angle by up to ~1.5e-2 rad and, through it, a few descriptor bins by a few LSB.  That is far inside what the
-    reference's own test accepts (test/test_keypoints.py: angle < 1e-1).  With the math builtins bound to siftmath
+    angle by up to 1.3e-2 rad and, through it, a few descriptor bins by up to 5 LSB (the measured worst cases; the bounds
+    asserted here, 2e-2 rad and 6 LSB, leave a small margin and no more).  That is far inside what the reference's own
+    test accepts (test/test_keypoints.py: angle < 1e-1).  With the math builtins bound to siftmath
     instead of glibc the reference kernels reproduce the oracle byte for byte (assert_same_keypoints).
     Returns a dict of the measured differences."""
     assert len(a) == len(b), "%s: %d vs %d keypoints" % (what, len(a), len(b))
@@ -88,7 +89,7 @@ def compare_keypoints_libm(a, b, what="", max_bad_rows=0.002, angle_abs=0.05, de
     assert dabs.max(initial=0) <= angle_abs, "%s: angle differs by %g rad" % (what, dabs.max())
     dd = np.abs(a["desc"].astype(np.int16) - b["desc"].astype(np.int16))
     assert dd.max(initial=0) <= desc_lsb, "%s: descriptor bins differ by %d" % (what, dd.max())
-    bad = int(((da > 2) | (dd.max(axis=1) > 0)).sum()) if len(a) else 0
+    bad = int(((ds > 0) | (da > 2) | (dd.max(axis=1) > 0)).sum()) if len(a) else 0     # scale differences count as well
     assert bad <= max(2, max_bad_rows * len(a)), "%s: %d of %d rows differ" % (what, bad, len(a))
     return dict(rows=len(a), rows_differing=bad, scale_ulp=int(ds.max(initial=0)), angle_ulp=int(da.max(initial=0)),
                 angle_rad=float(dabs.max(initial=0)), desc_bins_differing=int((dd > 0).sum()), desc_lsb=int(dd.max(initial=0)))

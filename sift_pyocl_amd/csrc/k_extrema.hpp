@@ -116,7 +116,9 @@ __device__ __forceinline__ void ext_edge_filter(const BlurPlanes &b, int W, floa
 template <int BUF, bool REFINE = false>
 __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H, int border, int rows, bool active, int sx, int sy,
                                               double contrast, float edth, float4 *__restrict__ cand, int *__restrict__ counter,
-                                              int capacity, ExtWaveLdsT<BUF> &L, int &pending, const RefineArgs *ra = nullptr) {
+                                              int capacity, ExtWaveLdsT<BUF> &L, int &pending, const RefineArgs *ra = nullptr,
+                                              int y_lo = -1, int y_hi = -1) {
+    if (y_lo < 0) { y_lo = border; y_hi = H - border; }
     auto refine_parked = [&]() {
         __builtin_amdgcn_wave_barrier();
         refine_candidates(b, W, H, L.buf, pending, ra->peak_thresh, ra->init_sigma, ra->kp, ra->kp_aux, ra->n_kp, ra->kp_capacity,
@@ -128,8 +130,8 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
     const int x = border + sx * 62 + lane - 1;
     const int xc = min(max(x, 0), W - 1);
     const bool col_ok = (lane >= 1) && (lane <= 62) && (x < W - border);
-    const int ya = border + sy * rows;
-    const int yb = active ? min(ya + rows, H - border) : ya - 2;
+    const int ya = y_lo + sy * rows;                     // (y_lo, y_hi) = (border, H - border), or one band of it
+    const int yb = active ? min(ya + rows, y_hi) : ya - 2;
     int tested = pending;                                // entries parked by earlier strips have had their edge test
 
     // Row loop: loads address a plane as SGPR base + one 32-bit byte offset shared by the six planes, advanced by a row
@@ -231,18 +233,20 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
 template <bool REFINE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REFINE ? 4 : SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
                                                       float edth, float4 *__restrict__ cand,
-                                                      int *__restrict__ counter, int capacity, RefineArgs ra) {
+                                                      int *__restrict__ counter, int capacity, RefineArgs ra,
+                                                      int y_lo, int y_hi) {      // rows [y_lo, y_hi) of the detection area (a band), or -1: all of it
     __shared__ ExtWaveLds lds_all[4];
     __shared__ int s_pending[4], s_base;
     const int lane = threadIdx.x & 63;
     ExtWaveLds &L = lds_all[threadIdx.x >> 6];
+    if (y_lo < 0) { y_lo = border; y_hi = H - border; }
     const int nx = (W - 2 * border + 61) / 62;
-    const int ny = (H - 2 * border + rows - 1) / rows;
+    const int ny = (y_hi - y_lo + rows - 1) / rows;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
     int pending = 0;                                     // candidates parked in L.buf (wave uniform)
     extrema_strip<SIFT_EXT_BUF, REFINE>(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand,
-                                        counter, capacity, L, pending, &ra);
+                                        counter, capacity, L, pending, &ra, y_lo, y_hi);
     if (REFINE) return;                                  // every survivor is already in the keypoint list
     // ---- what is left leaves with one atomicAdd per workgroup
     if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
@@ -344,11 +348,12 @@ __global__ __launch_bounds__(256) void refine_kernel(BlurPlanes b, int W, int H,
                                                      float peak_thresh, float init_sigma,
                                                      float4 *__restrict__ kp, int *__restrict__ kp_aux,
                                                      int *__restrict__ n_kp, int kp_capacity, int oct,
-                                                     int *__restrict__ overflow) {
+                                                     int *__restrict__ overflow, const int *__restrict__ first) {   // first: start of this band's candidates, or null
     const int n = min(*n_cand, cand_capacity);
     if (blockIdx.x == 0 && threadIdx.x == 0 && *n_cand > cand_capacity && overflow) *overflow = 1;
+    const int start = first ? *first : 0;
     refine_candidates(b, W, H, cand, n, peak_thresh, init_sigma, kp, kp_aux, n_kp, kp_capacity, oct,
-                      blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+                      start + blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // Stand-alone compaction (stage replay of algebra.cl:57-84 as called at plan.py:758-795): entries [start, end) of `in`

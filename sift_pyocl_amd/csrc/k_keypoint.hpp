@@ -65,13 +65,15 @@ __device__ __forceinline__ int div_exact(int idx, int d, float inv, int &rem) {
 // octave: group 0 = octave 0 (starts as soon as its pyramid exists), group 1 = all later octaves
 // (whose few keypoints would otherwise pay one latency-bound launch chain per octave).
 #define SIFT_MAX_OCTAVES 24
-#define SIFT_GROUPS 2
+#define SIFT_GROUPS 9     // octave 0 in up to 8 horizontal bands (pipelined detection -> orientation -> description) + the later octaves
 struct Counters {
     int n_out;                          // oriented keypoints so far (index into the record list)
     int overflow;                       // set when a list hit its capacity
     int n_kp;                           // refined keypoints so far, all octaves
     int tail_timeout;                   // octave_tail_kernel: a workgroup stopped waiting for the octave above (k_tail.hpp)
-    int grp_kp_start[SIFT_GROUPS + 1];  // refined-list start of each group
+    int grp_kp_start[SIFT_GROUPS + 1];  // refined-list range of each group: the start is set when the previous group closes,
+    int grp_kp_end[SIFT_GROUPS + 1];    // the end by mark_kp_kernel (banded groups: refinement of the next band runs beside this one's orientation)
+    int grp_cand_start[SIFT_GROUPS + 1];// candidate-list start of each band of octave 0 (one list, one counter for all of them)
     int grp_out_start[SIFT_GROUPS + 1]; // record-list range of each group, closed by mark_group_kernel
     int grp_out_end[SIFT_GROUPS + 1];
     int n_cand[SIFT_MAX_OCTAVES];       // candidates per octave
@@ -89,17 +91,28 @@ struct OctaveTable {
 
 // Runs after the orientation kernel of group g: freezes the group's record range (the descriptor kernel of g
 // may then run while the next group appends) and opens the next group's ranges.
-__global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_capacity) {
+// `kp_too`: also open the next group's refined-list range here (groups whose refinement waits for this kernel); banded
+// groups have had it opened by mark_kp_kernel already.
+__global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_capacity, int kp_too) {
     const int kp_end = min(c->n_kp, kp_capacity), out_end = min(c->n_out, out_capacity);
     c->grp_out_end[g] = out_end;
-    c->grp_kp_start[g + 1] = kp_end;
+    if (kp_too) c->grp_kp_start[g + 1] = kp_end;
     c->grp_out_start[g + 1] = out_end;
+}
+
+// Runs after the refinement of band g of octave 0: freezes the band's refined-list range (its orientation pass may then
+// run while the next band's refinement appends behind it) and opens the next band's refined / candidate ranges.
+__global__ void mark_kp_kernel(Counters *c, int g, int kp_capacity, int oct, int cand_capacity) {
+    const int kp_end = min(c->n_kp, kp_capacity);
+    c->grp_kp_end[g] = kp_end;
+    c->grp_kp_start[g + 1] = kp_end;
+    c->grp_cand_start[g + 1] = min(c->n_cand[oct], cand_capacity);
 }
 
 __global__ void begin_image_kernel(Counters *c) {
     const int t = threadIdx.x;
     if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; c->tail_timeout = 0; c->mm[0] = 0xffffffffu; c->mm[1] = 0u; }
-    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; c->desc_next[t] = 0; }
+    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_kp_end[t] = 0; c->grp_cand_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; c->desc_next[t] = 0; }
     if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
     if (t < 8) c->tail_ready[t] = 0;
 }
@@ -165,19 +178,21 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                                                           const float4 *__restrict__ kp,
                                                           const int *__restrict__ kp_aux, Counters *cnt, int group,
                                                           int kp_capacity, float4 *__restrict__ okp,
-                                                          int *__restrict__ oaux, int out_capacity, int team_below) {
+                                                          int *__restrict__ oaux, int out_capacity, int team_below, int end_marked, int small_blocks) {
     __shared__ OriWaveLds lds_all[4];
     __shared__ double fold[36];
     const int lane = threadIdx.x & 63;
     OriWaveLds &L = lds_all[threadIdx.x >> 6];
-    const int n = min(cnt->n_kp, kp_capacity);
+    // end of the group's refined keypoints: everything refined so far, or -- a band of octave 0, whose successor is being
+    // refined right now -- the end frozen by mark_kp_kernel
+    const int n = end_marked ? cnt->grp_kp_end[group] : min(cnt->n_kp, kp_capacity);
     const int first = cnt->grp_kp_start[group];
     // The launch is sized for a dense group (4096 workgroups: finer strides balance better, 154 k-keypoint frame -3.6 %);
     // the count, known here only, cuts it down for smaller groups (the rest of the chip is busy with the later octaves'
     // pyramid at that point: 9 k keypoints on 512 workgroups 0.893 ms per call, on 1024 0.907).  A workgroup beyond the
     // cut has nothing parked and nothing to wait for.
     const int count = n - first;
-    const int nblocks = min((int)gridDim.x, count < 16384 ? 512 : (count < 65536 ? 1024 : 4096));
+    const int nblocks = min((int)gridDim.x, count < 16384 ? small_blocks : (count < 65536 ? max(1024, small_blocks) : 4096));
     if ((int)blockIdx.x >= nblocks) return;
     siftmath::load_atan_fold(fold);
     if (lane < 36) L.mask[lane] = make_uint2(0u, 0u);

@@ -118,6 +118,12 @@ struct Options {
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
     int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
     int chain0 = 1;          // octave 0 end to end on the pyramid stream, later octaves' pyramids on the second chain
+    int bands = 0;           // octave 0 of a large frame: detection -> orientation -> description pipelined over this many horizontal bands (<= 1: off).
+                             // Measured (headline frame, interleaved A/B): 0 bands 0.867 ms, 2: 0.962, 4: 1.028, 8: 1.348 -- a launch over a
+                             // quarter of the keypoints lasts as long as its slowest keypoint (~120 us with a wave per keypoint), the bands'
+                             // descriptor launches run one after the other, and the small detection / orientation launches each pay their
+                             // ramp: the serial phases are cheaper than the pipeline.  Kept for experiments, off.
+    int ori_small_blocks = 512;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
 };
@@ -153,6 +159,9 @@ struct siftmi_plan {
     float *tmp = nullptr;         // generic blur only
     hipStream_t stream2 = nullptr;            // detection / description of octave 0 (overlaps the next octaves' pyramid)
     hipStream_t stream3 = nullptr;            // detection / description of the later octaves (overlaps group 0's descriptors)
+    hipStream_t stream4 = nullptr;            // banded octave 0: the descriptor launches of the bands (created on first use)
+    std::vector<hipEvent_t> ev_kp, ev_out;    // banded octave 0: band b refined (its range frozen) / band b oriented
+    int bands_last = 0;                       // bands of octave 0 in the image enqueued last (0: not banded)
     hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr, ev_det = nullptr;
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
@@ -452,7 +461,9 @@ OctaveTable octave_table(const siftmi_plan *p) {
 
 // extrema of the three detection scales + sub-pixel refinement of one octave; survivors are appended to the
 // image-wide refined list (tagged with the octave)
-void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
+// band < 0: the whole octave.  band >= 0 (of nbands, octave 0 of a large frame): the band's strips only, candidates
+// appended behind the previous band's, refinement from there on, and mark_kp_kernel closes the band's refined range.
+void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int band = -1, int nbands = 1) {
     const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
     const int octsize = 1 << oct;
     char lab[96];
@@ -462,33 +473,41 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
     const int kcap = (int)p->kpsize;
     if (W > 2 * border && H > 2 * border) {
         const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border);
-        const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
-        const int blocks = (nx * ny + 3) / 4;
+        const int nx = (W - 2 * border + 61) / 62, ny_all = (H - 2 * border + rows - 1) / rows;
+        int y_lo = -1, y_hi = -1, ny = ny_all;
+        if (band >= 0) {                     // whole strips: band b takes strips [b * ny / B, (b + 1) * ny / B)
+            const int s0 = (int)((int64_t)band * ny_all / nbands), s1 = (int)((int64_t)(band + 1) * ny_all / nbands);
+            y_lo = border + s0 * rows; y_hi = std::min(border + s1 * rows, H - border);
+            ny = s1 - s0;
+        }
+        const int blocks = std::max(1, (nx * ny + 3) / 4);
         const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
         const RefineArgs ra = {p->par.peak_thresh, (float)p->par.init_sigma, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, oct};
         // One launch detects and refines (the survivors of the edge test are refined by the wave that parked them: no
         // candidate list, no second launch) unless every stage is bracketed on its own (full profile) or option
         // "fused_refine" says otherwise (0: never, 1: planes below 1400^2, 2: every plane).
-        const bool fused = p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
+        const bool fused = band < 0 && p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
         if (fused) {
             snprintf(lab, sizeof lab, "local_maxmin+interp_keypoint %d", oct);
             Scope sc(p, lab, false, 0, st);
             hipLaunchKernelGGL(extrema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                               contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra);
+                               contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra, -1, -1);
             return;
         }
         snprintf(lab, sizeof lab, "local_maxmin %d", oct);
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra);
+                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra, y_lo, y_hi);
     }
     {
         snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)p->cand,
                            (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
-                           p->kp_scale, &p->cnt->n_kp, kcap, oct, &p->cnt->overflow);
+                           p->kp_scale, &p->cnt->n_kp, kcap, oct, &p->cnt->overflow,
+                           band >= 0 ? (const int *)&p->cnt->grp_cand_start[band] : (const int *)nullptr);
     }
+    if (band >= 0) hipLaunchKernelGGL(mark_kp_kernel, dim3(1), dim3(1), 0, st, p->cnt, band, kcap, oct, kcap);
 }
 
 // First octave of the run that octave_tail_kernel takes (k_tail.hpp), or n_oct when it takes none: octaves >= 1 whose
@@ -547,8 +566,9 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
     return SIFTMI_OK;
 }
 
-// orientation + descriptor for every refined keypoint of one group of octaves
-void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
+// orientation of every refined keypoint of one group, then the group's record range is frozen (mark_group_kernel).
+// banded: the group is a band of octave 0 -- its refined range was frozen by mark_kp_kernel, the next band is being refined.
+void launch_orient_group(siftmi_plan *p, int group, hipStream_t st, bool banded) {
     const int kcap = (int)p->kpsize;
     const OctaveTable tab = octave_table(p);
     char lab[96];
@@ -557,28 +577,41 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st) {
         Scope sc(p, lab, false, 0, st);
         const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
         hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team);
+                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
+                           banded ? 1 : 0, p->opt.ori_small_blocks);
     }
-    hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap);
-    if (group == 0 && p->overlap) hipEventRecord(p->ev_mark0, st);   // later octaves may start appending now
-    {
-        snprintf(lab, sizeof lab, "descriptors group %d", group);
-        Scope sc(p, lab, false, 0, st);
-        const int desc_blocks = p->opt.desc_blocks;
-        // Optional residency throttle (option "desc_pad": bytes of unused dynamic LDS per workgroup).  Round 1 capped the
-        // octave-0 launch at 3 workgroups per CU so that the later octaves' kernels found registers; with the round-2
-        // kernels (shorter detection chain, 4 workgroups per CU by registers) the unthrottled launch is faster
-        // (0.96 against 1.01 ms per 4096^2 frame), so the default is 0.
-        const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
-        if (p->desc_rows && !p->opt.desc_stream) {
-            // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
-            // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
-            hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks);
-        } else
-            hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
-    }
+    hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap, banded ? 0 : 1);
+}
+
+// descriptors of one group's oriented keypoints
+void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
+    const int kcap = (int)p->kpsize;
+    const OctaveTable tab = octave_table(p);
+    char lab[96];
+    snprintf(lab, sizeof lab, "descriptors group %d", group);
+    Scope sc(p, lab, false, 0, st);
+    const int desc_blocks = p->opt.desc_blocks;
+    // Optional residency throttle (option "desc_pad": bytes of unused dynamic LDS per workgroup).  Round 1 capped the
+    // octave-0 launch at 3 workgroups per CU so that the later octaves' kernels found registers; with the round-2
+    // kernels (shorter detection chain, 4 workgroups per CU by registers) the unthrottled launch is faster
+    // (0.96 against 1.01 ms per 4096^2 frame), so the default is 0.
+    const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
+    if (p->desc_rows && !p->opt.desc_stream) {
+        // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
+        // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
+        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
+                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks);
+    } else
+        hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
+                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
+}
+
+// orientation + descriptor for every refined keypoint of one group of octaves, on one stream; `mark_event`: recorded once
+// the group's ranges are frozen (the next group may start appending)
+void launch_describe_group(siftmi_plan *p, int group, hipStream_t st, hipEvent_t mark_event = nullptr) {
+    launch_orient_group(p, group, st, false);
+    if (mark_event) hipEventRecord(mark_event, st);
+    launch_descriptor_group(p, group, st);
 }
 
 }  // namespace
@@ -701,6 +734,9 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
     if (p->stream3) { hipStreamSynchronize(p->stream3); hipStreamDestroy(p->stream3); }
+    if (p->stream4) { hipStreamSynchronize(p->stream4); hipStreamDestroy(p->stream4); }
+    for (hipEvent_t e : p->ev_kp) hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_out) hipEventDestroy(e);
     if (p->ev_mark0) hipEventDestroy(p->ev_mark0);
     if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
     if (p->ev_det) hipEventDestroy(p->ev_det);
@@ -764,6 +800,8 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
     else if (n == "chain0") o.chain0 = v != 0;
+    else if (n == "ori_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_small_blocks must be >= 1"); o.ori_small_blocks = v; }
+    else if (n == "bands") { if (v < 0 || v >= SIFT_GROUPS) return fail(SIFTMI_EINVAL, "bands must be in 0..%d", SIFT_GROUPS - 1); o.bands = v; }
     else if (n == "tile") o.tile = (int)v;
     else if (n == "ext_rows") o.ext_rows = (int)v;
     else if (n == "tail") o.tail = v != 0;
@@ -893,6 +931,26 @@ int enqueue_body(siftmi_plan *p) {
     const bool two = p->overlap && p->n_oct > 0;
     const bool chain0 = two && p->opt.chain0;
     const int tail_first = tail_first_octave(p);
+    // Banded octave 0 (option "bands", large frames, chain0 layout): detection + refinement of band b on `stream` (one after
+    // the other, behind the pyramid), its orientation on `stream2` as soon as its refined range is frozen (ev_kp[b]), its
+    // descriptors on `stream4` as soon as its record range is (ev_out[b]).  Unbanded, the three phases of octave 0 are
+    // strictly serial -- 96 + 20 + 70 us on the headline frame before the first descriptor wave starts -- and the
+    // memory-bound detection never overlaps the issue-bound description.  Groups 0 .. nbands - 1 are the bands, group
+    // `later` the later octaves.
+    int nbands = 0;
+    if (chain0 && p->opt.bands > 1 && p->n_oct > 0 && p->profile <= 1 && march_plane(p->ow[0], p->oh[0]) && tail_first != 0 &&
+        p->ow[0] > 2 * p->par.border_dist && p->oh[0] > 2 * p->par.border_dist) {
+        nbands = std::min(p->opt.bands, SIFT_GROUPS - 1);
+        if (!p->stream4) HIPCHK(hipStreamCreateWithFlags(&p->stream4, hipStreamNonBlocking));
+        while ((int)p->ev_kp.size() < nbands) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            p->ev_kp.push_back(a); p->ev_out.push_back(b);
+        }
+    }
+    p->bands_last = nbands;
+    const int later = nbands ? nbands : 1;         // group index of the later octaves
     auto pyramid_stream = [&](int oct) { return (chain0 && oct > 0) ? p->stream3 : p->stream; };                                   // builds an octave's planes
     // Later octaves: the pyramid of octave o+1 needs only plane 3 of octave o, not its detection.  With "split_detect" the
     // extrema / refinement launches of octaves >= 1 go to `stream2` (idle in the chain0 layout), each behind the event
@@ -958,7 +1016,7 @@ int enqueue_body(siftmi_plan *p) {
                 HIPCHK(hipEventRecord(p->ev_det, p->stream2));
                 HIPCHK(hipStreamWaitEvent(ts, p->ev_det, 0));
             }
-            launch_describe_group(p, 1, ts);
+            launch_describe_group(p, later, ts);
             if (two) HIPCHK(hipEventRecord(p->ev_grp1, ts));
             break;
         }
@@ -971,15 +1029,28 @@ int enqueue_body(siftmi_plan *p) {
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
             if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
         }
+        if (oct == 0 && nbands) {
+            for (int b = 0; b < nbands; b++) {
+                launch_detect_octave(p, 0, p->stream, b, nbands);
+                HIPCHK(hipEventRecord(p->ev_kp[(size_t)b], p->stream));
+                HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_kp[(size_t)b], 0));
+                launch_orient_group(p, b, p->stream2, true);
+                HIPCHK(hipEventRecord(p->ev_out[(size_t)b], p->stream2));
+                HIPCHK(hipStreamWaitEvent(p->stream4, p->ev_out[(size_t)b], 0));
+                launch_descriptor_group(p, b, p->stream4);
+            }
+            HIPCHK(hipEventRecord(p->ev_mark0, p->stream2));     // every range of octave 0 is frozen: the later octaves may append
+            continue;
+        }
         launch_detect_octave(p, oct, dst);
-        if (oct == 0) launch_describe_group(p, 0, dst);
+        if (oct == 0) launch_describe_group(p, 0, dst, p->overlap ? p->ev_mark0 : nullptr);
         else if (oct == p->n_oct - 1) {
             hipStream_t ds = two ? p->stream3 : p->stream;        // group 1 is described (and the image ends) on stream3
             if (dst != ds) {
                 HIPCHK(hipEventRecord(p->ev_det, dst));
                 HIPCHK(hipStreamWaitEvent(ds, p->ev_det, 0));
             }
-            launch_describe_group(p, 1, ds);
+            launch_describe_group(p, later, ds);
             if (two) HIPCHK(hipEventRecord(p->ev_grp1, ds));
         }
     }
@@ -991,7 +1062,7 @@ int enqueue_body(siftmi_plan *p) {
     // launches: small images are bound by the GPU-side latency of dependent kernels, not by host launch cost.)
     p->wait_a = p->stream; p->wait_b = nullptr;
     if (two) {
-        hipStream_t end0 = chain0 ? p->stream : p->stream2;
+        hipStream_t end0 = nbands ? p->stream4 : (chain0 ? p->stream : p->stream2);
         if (p->profile) hipEventRecord(p->ev_last, end0);
         HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, end0));
         p->wait_a = end0;
@@ -1010,7 +1081,7 @@ int enqueue_body(siftmi_plan *p) {
 
 // wait for everything in flight on the plan's streams, ignoring errors (error paths only)
 static void drain_streams(siftmi_plan *p) {
-    for (hipStream_t s : {p->stream, p->stream2, p->stream3})
+    for (hipStream_t s : {p->stream, p->stream2, p->stream3, p->stream4})
         if (s) (void)hipStreamSynchronize(s);
 }
 
@@ -1049,7 +1120,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     int ovf = hc.overflow | p->hb->c.overflow | (p->wait_b ? p->hb->c2.overflow : 0);
     if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
     p->last_count = n;
-    p->last_group0 = hc.grp_out_end[0] - hc.grp_out_start[0];
+    p->last_group0 = hc.grp_out_end[p->bands_last ? p->bands_last - 1 : 0] - hc.grp_out_start[0];
     *n_out = n;
     if (overflow) *overflow = ovf;
     return SIFTMI_OK;
@@ -1328,7 +1399,7 @@ void batch_drain(siftmi_batch *b) {
         if (b->lane_image[l] < 0) continue;
         siftmi_plan *p = b->lanes[l];
         if (hipSetDevice(p->device) == hipSuccess) {
-            for (hipStream_t s : {p->stream, p->stream2, p->stream3})
+            for (hipStream_t s : {p->stream, p->stream2, p->stream3, p->stream4})
                 if (s) (void)hipStreamSynchronize(s);
         }
         b->lane_image[l] = -1;
@@ -1843,7 +1914,7 @@ int siftmi_stage_local_maxmin(int32_t dev, const float *blurs, int32_t W, int32_
         const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
         const float edth = (octsize <= 1) ? par->edge_thresh0 : par->edge_thresh;
         hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border, rows,
-                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity, RefineArgs{});
+                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity, RefineArgs{}, -1, -1);
     }
     if ((rc = stage_end())) return rc;
     Counters hc;
@@ -1870,7 +1941,7 @@ int siftmi_stage_interp(int32_t dev, const float *blurs, int32_t W, int32_t H, c
     Counters *dc = cnt.as<Counters>();
     hipLaunchKernelGGL(refine_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, 0, bp, W, H, (const float4 *)c.as<float4>(),
                        (const int *)&dc->n_cand[0], (int)n, par->peak_thresh, (float)par->init_sigma, k.as<float4>(),
-                       ks.as<int>(), &dc->n_kp, (int)n, 0, (int *)nullptr);
+                       ks.as<int>(), &dc->n_kp, (int)n, 0, (int *)nullptr, (const int *)nullptr);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
     const int64_t m = hc.n_kp;
@@ -1938,7 +2009,7 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
                        par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
-                       o.as<float4>(), oa.as<int>(), (int)capacity, 0);
+                       o.as<float4>(), oa.as<int>(), (int)capacity, 0, 0, 512);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
     int64_t m = hc.n_out < capacity ? hc.n_out : capacity;

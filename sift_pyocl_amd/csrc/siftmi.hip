@@ -118,6 +118,8 @@ struct Options {
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
     int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
     int chain0 = 1;          // octave 0 end to end on the pyramid stream, later octaves' pyramids on the second chain
+    int early_chain = 0;     // later octaves' chain starts when plane 3 of octave 0 exists (after its third blur), not after its fifth:
+                             // interleaved A/B 4096^2 0.854 -> 0.894 ms, 2048^2 0.523 -> 0.530 (octave 0's last two blurs slow down by more than the chain gains): off
     int bands = 0;           // octave 0 of a large frame: detection -> orientation -> description pipelined over this many horizontal bands (<= 1: off).
                              // Measured (headline frame, interleaved A/B): 0 bands 0.867 ms, 2: 0.962, 4: 1.028, 8: 1.348 -- a launch over a
                              // quarter of the keypoints lasts as long as its slowest keypoint (~120 us with a wave per keypoint), the bands'
@@ -162,7 +164,7 @@ struct siftmi_plan {
     hipStream_t stream4 = nullptr;            // banded octave 0: the descriptor launches of the bands (created on first use)
     std::vector<hipEvent_t> ev_kp, ev_out;    // banded octave 0: band b refined (its range frozen) / band b oriented
     int bands_last = 0;                       // bands of octave 0 in the image enqueued last (0: not banded)
-    hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr, ev_det = nullptr;
+    hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr, ev_det = nullptr, ev_p3 = nullptr;
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
@@ -738,6 +740,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     for (hipEvent_t e : p->ev_kp) hipEventDestroy(e);
     for (hipEvent_t e : p->ev_out) hipEventDestroy(e);
     if (p->ev_mark0) hipEventDestroy(p->ev_mark0);
+    if (p->ev_p3) hipEventDestroy(p->ev_p3);
     if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
     if (p->ev_det) hipEventDestroy(p->ev_det);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
@@ -800,6 +803,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
     else if (n == "chain0") o.chain0 = v != 0;
+    else if (n == "early_chain") o.early_chain = v != 0;
     else if (n == "ori_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_small_blocks must be >= 1"); o.ori_small_blocks = v; }
     else if (n == "bands") { if (v < 0 || v >= SIFT_GROUPS) return fail(SIFTMI_EINVAL, "bands must be in 0..%d", SIFT_GROUPS - 1); o.bands = v; }
     else if (n == "tile") o.tile = (int)v;
@@ -960,12 +964,14 @@ int enqueue_body(siftmi_plan *p) {
     bool built[SIFT_MAX_OCTAVES] = {false};
     bool handed[SIFT_MAX_OCTAVES + 1] = {false};   // plane 0 of the octave was written by the blur launch of the octave above
     // shrink + five blurs of one octave on its pyramid stream (once)
+    const bool early0 = chain0 && p->opt.early_chain && p->n_oct > 1 && p->profile <= 1;
+    if (early0 && !p->ev_p3) HIPCHK(hipEventCreateWithFlags(&p->ev_p3, hipEventDisableTiming));
     auto build_pyramid = [&](int oct) -> int {
         if (built[oct]) return SIFTMI_OK;
         built[oct] = true;
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
         hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
-        if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
+        if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, (early0 && p->ev_p3) ? p->ev_p3 : p->ev_pyr[0], 0));
         if (oct > 0 && !handed[oct]) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
@@ -985,14 +991,19 @@ int enqueue_body(siftmi_plan *p) {
                 if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
                 p->chain = ch;
             }
-            for (int s = 0; s < 5; s++)
+            for (int s = 0; s < 5; s++) {
                 if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
+                if (s == 2 && oct == 0 && early0) HIPCHK(hipEventRecord(p->ev_p3, pyr));     // plane 3 (and the hand-off) exist
+            }
             if (oct == 0) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }
         } else {
             for (int s = 0; s < 5; s++) {
                 snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
-                Scope sc(p, lab, true, (double)W * H, pyr, oct);
-                if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
+                {
+                    Scope sc(p, lab, true, (double)W * H, pyr, oct);
+                    if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
+                }
+                if (s == 2 && oct == 0 && early0) HIPCHK(hipEventRecord(p->ev_p3, pyr));
             }
         }
         if (two && (oct == 0 || pyr != dst)) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));

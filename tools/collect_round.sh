@@ -1,7 +1,7 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r02
+# Collect the rocprofv3 evidence of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r03
 # -> gpurun_out/round_<tag>/ ; copy what should be judged into profiles/<tag>/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -13,7 +13,8 @@ cp gpurun_out/prof_$TAG/blur_traffic.json $OUT/ 2>/dev/null
 python tools/stage_profile.py 4096 white 3 > $OUT/stage_white4096.txt 2>&1
 python tools/stage_profile.py 4096 smooth 0 > $OUT/stage_smooth4096.txt 2>&1
 bash tools/dev/trace_gaps.sh > $OUT/timeline_white4096.txt 2>&1
-for k in descriptor_kernel orientation_kernel extrema_kernel; do bash tools/dev/pmc_kernel.sh $k > $OUT/pmc_$k.txt 2>&1; done
+for k in descriptor_kernel orientation_kernel; do bash tools/dev/pmc_split.sh $k > $OUT/pmc_$k.txt 2>&1; done   # (group 0, group 1) launches apart
+bash tools/dev/pmc_kernel.sh extrema_kernel > $OUT/pmc_extrema_kernel.txt 2>&1
 python tools/bench_match.py > $OUT/match_100k.txt 2>&1
 python tools/dev/quick_smooth.py > $OUT/configs.txt 2>&1
 python tools/dev/small_frames.py tail 1 0 sizes=256,512,1024,2048 > $OUT/small_frames.txt 2>&1

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_W
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
                        int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
-                       int team_below, int dynamic, int dense_blocks) {
+                       int team_below, int dynamic, int dense_blocks, int small_blocks) {
     __shared__ DescLds lds;
     __shared__ double fold[36];
     int start = range_start, end = range_end;
@@ -719,7 +719,11 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
     else {
         // three workgroups per CU instead of four on a dense group: 154 k keypoints 5.56 -> 5.45 ms per call (the 9 k
         // keypoints of the headline frame prefer the full set: 0.903 against 0.927 ms)
-        const int nblocks = (end - start >= 65536) ? min((int)gridDim.x, dense_blocks) : (int)gridDim.x;
+        // ... and 576 on a group of fewer than 16384: such a group never is the whole frame's work, the later octaves' chain
+        // runs beside it and ends the image (round 3, headline frame: 960 workgroups 0.857 ms, 576: 0.836, 448: 0.863; a
+        // 39 k-keypoint group wants all 960: 1.55 against 1.72 ms at 640)
+        const int count = end - start;
+        const int nblocks = count >= 65536 ? min((int)gridDim.x, dense_blocks) : (count < 16384 ? min((int)gridDim.x, small_blocks) : (int)gridDim.x);
         if ((int)blockIdx.x >= nblocks) return;
         descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
                          (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr, nblocks);

@@ -103,6 +103,7 @@ struct Options {
     // 1024 = every wave slot of the chip, which starves the other stream's kernels for the whole launch -- 1024^2 smooth
     // frame 0.760 ms, with 896-960 workgroups 0.671; 2048^2 smooth 1.85 -> 1.73), bytes of dynamic LDS (residency throttle)
     int desc_blocks = 960, desc_pad = 0;
+    int desc_small_blocks = 576;   // ... and for groups of fewer than 16384 (the later octaves' chain needs the room)
     int desc_dense_blocks = 832;   // ... and for groups of >= 65536 keypoints (704: 5.47 ms per 154 k-keypoint call, 768-896: 5.27, 960: 5.31)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
@@ -598,11 +599,14 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
     // kernels (shorter detection chain, 4 workgroups per CU by registers) the unthrottled launch is faster
     // (0.96 against 1.01 ms per 4096^2 frame), so the default is 0.
     const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
+    // a small group 0 of a LARGE frame leaves room for the later octaves' chain, which ends such an image (4096^2 headline
+    // -2.2 %, 4096^2 with every octave -2.5 %); on a 1024^2 frame that chain is short and the same cut costs 2 %
+    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
     if (p->desc_rows && !p->opt.desc_stream) {
         // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
         // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
         hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks);
+                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
     } else
         hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                            (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
@@ -817,6 +821,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
     else if (n == "fused_shrink") o.fused_shrink = v != 0;
     else if (n == "fused_refine") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fused_refine must be 0, 1 or 2"); o.fused_refine = (int)v; }
+    else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
@@ -2059,7 +2064,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
         if (block_ok)
             hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30);
+                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,

@@ -342,3 +342,47 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
             return local
         return {i: k for i, k in zip(mine, local)}
     return gather_records(local, len(images), rank, world_size, device=device)
+
+
+def match_sharded(kp1, kp2, plan=None, rank=None, world_size=None, device=None, matcher=None):
+    """``MatchPlan.match(kp1, kp2, raw_results=True)`` with the QUERIES split over the ranks: rank r scans the
+    contiguous slice ``kp1[r * n1 // N : (r + 1) * n1 // N]`` against the whole second list (every rank holds it: 14.4 MB
+    at 100 k keypoints), then one all-gather of the pair counts and one of the (i, j) pairs -- a query's result does not
+    depend on any other query (matching_cpu.cl:67-108), so the union is the single-device result (in rank order; the
+    reference does not define an order either).  Every rank returns all the pairs.
+
+    :param kp1, kp2: host recarrays of 144-byte records, the same on every rank
+    :param plan: a ``MatchPlan`` of this rank (created when None); `matcher(a, b) -> (n, 2) int array` replaces it (tests)
+    """
+    import torch
+    import torch.distributed as dist
+
+    if rank is None or world_size is None:
+        if dist.is_available() and dist.is_initialized():
+            rank, world_size = dist.get_rank(), dist.get_world_size()
+        else:
+            rank, world_size = 0, 1
+    n1 = len(kp1)
+    lo, hi = rank * n1 // world_size, (rank + 1) * n1 // world_size
+    if matcher is None:
+        if plan is None:
+            from .match import MatchPlan
+            plan = MatchPlan(size=max(1, min(hi - lo, len(kp2))))
+        matcher = lambda a, b: plan.match(a, b, raw_results=True)      # noqa: E731
+    mine = numpy.asarray(matcher(kp1[lo:hi], kp2), dtype=numpy.int32).reshape(-1, 2) if hi > lo and len(kp2) else numpy.empty((0, 2), numpy.int32)
+    mine = mine.copy()
+    mine[:, 0] += lo
+    if world_size == 1:
+        return mine
+    nccl = dist.get_backend() == "nccl"
+    dev = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu"))
+    counts = torch.empty(world_size, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([len(mine)], dtype=torch.int64, device=dev))
+    counts = counts.cpu().tolist()
+    width = max(1, max(counts))
+    payload = torch.zeros((width, 2), dtype=torch.int32)
+    payload[:len(mine)] = torch.from_numpy(mine)
+    gathered = torch.empty((world_size * width, 2), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered, payload.to(dev))
+    gathered = gathered.cpu().numpy().reshape(world_size, width, 2)
+    return numpy.concatenate([gathered[r, :counts[r]] for r in range(world_size)], axis=0)

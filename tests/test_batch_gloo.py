@@ -88,6 +88,47 @@ def test_gather_records_device_form_world2(n_items):
     assert results[0] == expected and results[1] == expected
 
 
+def _worker_match(rank, world, port, q):
+    """match_sharded over gloo: queries split over two ranks, the CPU oracle as the matcher"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SIFTMI_STANDALONE"] = "1"
+    import torch.distributed as dist
+    from oracle import pyoracle
+    from sift_pyocl_amd.batch import match_sharded
+    from util import smooth_noise
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = pyoracle.keypoints(smooth_noise((150, 180), seed=7))
+    b = pyoracle.keypoints(smooth_noise((150, 180), seed=7) + smooth_noise((150, 180), seed=8) * 0.05)
+    pairs = match_sharded(a, b, matcher=lambda x, y: pyoracle.match(x, y)[0])
+    q.put((rank, pairs.tobytes(), len(pairs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_match_sharded_world2():
+    import torch.multiprocessing as mp
+    from oracle import pyoracle
+    from util import smooth_noise, sort_rows
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_match, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a = pyoracle.keypoints(smooth_noise((150, 180), seed=7))
+    b = pyoracle.keypoints(smooth_noise((150, 180), seed=7) + smooth_noise((150, 180), seed=8) * 0.05)
+    want, total = pyoracle.match(a, b)
+    assert total > 20
+    for _, raw, n in results:
+        got = np.frombuffer(raw, dtype=np.int32).reshape(n, 2)
+        assert np.array_equal(sort_rows(got), sort_rows(want))
+
+
 def test_shard_indices():
     from sift_pyocl_amd.batch import shard_indices
     assert shard_indices(64, 3, 8) == list(range(3, 64, 8))

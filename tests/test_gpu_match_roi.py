@@ -4,7 +4,7 @@ reference's kernel built natively, tests/test_oracle_vs_ref.py)."""
 import numpy as np
 import pytest
 
-from util import dtype_kp, sort_rows
+from util import dtype_kp, smooth_noise, sort_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -99,3 +99,26 @@ def test_mutual_on_real_keypoints(siftlib, oracle):
     # strict: both ends of every pair are on the mask
     assert roi[rec[:, 0].y.astype(int), rec[:, 0].x.astype(int)].all() and roi[rec[:, 1].y.astype(int), rec[:, 1].x.astype(int)].all()
     assert abs(np.median(rec[:, 1].x - rec[:, 0].x) - 11.0) < 0.1 and abs(np.median(rec[:, 1].y - rec[:, 0].y) + 7.0) < 0.1
+
+
+def test_query_slices_equal_the_full_scan(siftlib):
+    """The multi-GPU form of MatchPlan (batch.match_sharded) splits the queries over the ranks: on the HIP path the union
+    of the slices' pairs (first index shifted by the slice start) must be the single-device result, and match_sharded
+    without a process group is that single-device call."""
+    import sift_pyocl_amd as sp
+    from sift_pyocl_amd.batch import match_sharded
+    img = smooth_noise((600, 700), seed=21)
+    plan = sp.SiftPlan(template=img)
+    a = plan.keypoints(img)
+    b = plan.keypoints(img + smooth_noise((600, 700), seed=22) * 0.03)
+    mp = sp.MatchPlan()
+    full = mp.match(a, b, raw_results=True)
+    assert len(full) > 50
+    parts = []
+    for r in range(3):
+        lo, hi = r * len(a) // 3, (r + 1) * len(a) // 3
+        part = mp.match(a[lo:hi], b, raw_results=True).copy()
+        part[:, 0] += lo
+        parts.append(part)
+    assert np.array_equal(sort_rows(np.concatenate(parts)), sort_rows(full))
+    assert np.array_equal(sort_rows(match_sharded(a, b, plan=mp)), sort_rows(full))

@@ -133,6 +133,11 @@ int siftmi_plan_last_kernel_ms(const siftmi_plan *plan, float *total_ms, float *
  * concurrently with another kernel of the plan, later octaves overlap the detection stream. */
 int siftmi_plan_blur_ms(const siftmi_plan *plan, int32_t octave, float *blur_ms, int32_t *blur_launches,
                         double *blur_pixels);
+/* running totals of the two figures above over every keypoints() call since the last reset (light profile): what a
+ * benchmark loop reads ONCE after its timed region instead of querying events after every call.
+ *   calls, total_ms (first -> last kernel of each call, summed), blur0_ms / blur0_launches / blur0_pixels (octave 0) */
+int siftmi_plan_profile_totals(siftmi_plan *plan, int32_t reset, int64_t *calls, double *total_ms, double *blur0_ms,
+                               int64_t *blur0_launches, double *blur0_pixels);
 int siftmi_plan_destroy(siftmi_plan *plan);
 
 /* ---- batched, pipelined keypoints -----------------------------------------------------------

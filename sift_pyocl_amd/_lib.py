@@ -54,6 +54,8 @@ _SIGNATURES = {
                                              C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "siftmi_plan_blur_ms": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_double)]),
+    "siftmi_plan_profile_totals": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "siftmi_plan_destroy": (C.c_int, [C.c_void_p]),
     "siftmi_match_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "siftmi_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,

@@ -165,6 +165,8 @@ struct siftmi_plan {
     hipStream_t stream4 = nullptr;            // banded octave 0: the descriptor launches of the bands (created on first use)
     std::vector<hipEvent_t> ev_kp, ev_out;    // banded octave 0: band b refined (its range frozen) / band b oriented
     int bands_last = 0;                       // bands of octave 0 in the image enqueued last (0: not banded)
+    int64_t acc_calls = 0, acc_b0_launches = 0;   // running totals of the light profile (siftmi_plan_profile_totals)
+    double acc_total_ms = 0, acc_b0_ms = 0, acc_b0_pixels = 0;
     hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr, ev_det = nullptr, ev_p3 = nullptr;
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
@@ -858,7 +860,7 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
 #ifdef SIFT_ABLATE
     apply_ablate();
 #endif
-    if (p->profile) hipEventRecord(p->ev_first, p->stream);
+    if (p->profile > 1) hipEventRecord(p->ev_first, p->stream);     // (light profile: only the blur bracket -- every event record between kernels is a bubble)
     hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt);
     const float *f32src = (const float *)src;
     // Typed frames (u8 / u16 / ... / RGB8) are converted at the point of use by the min/max and the initial blur
@@ -969,6 +971,7 @@ int enqueue_body(siftmi_plan *p) {
     bool built[SIFT_MAX_OCTAVES] = {false};
     bool handed[SIFT_MAX_OCTAVES + 1] = {false};   // plane 0 of the octave was written by the blur launch of the octave above
     // shrink + five blurs of one octave on its pyramid stream (once)
+    hipEvent_t pyr0_done = nullptr;            // light profile: the blur bracket's closing event stands in for ev_pyr[0]
     const bool early0 = chain0 && p->opt.early_chain && p->n_oct > 1 && p->profile <= 1;
     if (early0 && !p->ev_p3) HIPCHK(hipEventCreateWithFlags(&p->ev_p3, hipEventDisableTiming));
     auto build_pyramid = [&](int oct) -> int {
@@ -976,7 +979,7 @@ int enqueue_body(siftmi_plan *p) {
         built[oct] = true;
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
         hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
-        if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, (early0 && p->ev_p3) ? p->ev_p3 : p->ev_pyr[0], 0));
+        if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, (early0 && p->ev_p3) ? p->ev_p3 : (pyr0_done ? pyr0_done : p->ev_pyr[0]), 0));
         if (oct > 0 && !handed[oct]) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
@@ -1000,7 +1003,12 @@ int enqueue_body(siftmi_plan *p) {
                 if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
                 if (s == 2 && oct == 0 && early0) HIPCHK(hipEventRecord(p->ev_p3, pyr));     // plane 3 (and the hand-off) exist
             }
-            if (oct == 0) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }
+            if (oct == 0) {
+                Scope *ch = static_cast<Scope *>(p->chain);
+                const size_t idx = ch ? ch->idx : (size_t)-1;
+                delete ch; p->chain = nullptr;                  // records the bracket's closing event on `pyr`
+                if (idx != (size_t)-1 && two) pyr0_done = p->events[idx].b;   // ... which is also "octave 0's pyramid exists"
+            }
         } else {
             for (int s = 0; s < 5; s++) {
                 snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
@@ -1011,14 +1019,14 @@ int enqueue_body(siftmi_plan *p) {
                 if (s == 2 && oct == 0 && early0) HIPCHK(hipEventRecord(p->ev_p3, pyr));
             }
         }
-        if (two && (oct == 0 || pyr != dst)) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
+        if (two && (oct == 0 || pyr != dst) && !(oct == 0 && pyr0_done)) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
         return SIFTMI_OK;
     };
     for (int oct = 0; oct < p->n_oct; oct++) {
         hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
         if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp), then the group's descriptors
             hipStream_t ts = two ? p->stream3 : p->stream;        // the tail builds pyramids too: it stays on the pyramid chain
-            if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, p->ev_pyr[0], 0));
+            if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, pyr0_done ? pyr0_done : p->ev_pyr[0], 0));
             if (two) {
                 if (pyr != ts) {
                     HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
@@ -1043,7 +1051,7 @@ int enqueue_body(siftmi_plan *p) {
         if (oct == 0 && chain0 && p->opt.early_pyr && p->n_oct > 1 && tail_first != 1 && (rc = build_pyramid(1))) return rc;
         if (two) {
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
-            if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, p->ev_pyr[(size_t)oct], 0));
+            if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, (oct == 0 && pyr0_done) ? pyr0_done : p->ev_pyr[(size_t)oct], 0));
         }
         if (oct == 0 && nbands) {
             for (int b = 0; b < nbands; b++) {
@@ -1079,16 +1087,16 @@ int enqueue_body(siftmi_plan *p) {
     p->wait_a = p->stream; p->wait_b = nullptr;
     if (two) {
         hipStream_t end0 = nbands ? p->stream4 : (chain0 ? p->stream : p->stream2);
-        if (p->profile) hipEventRecord(p->ev_last, end0);
+        if (p->profile > 1) hipEventRecord(p->ev_last, end0);
         HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, end0));
         p->wait_a = end0;
         if (p->n_oct > 1) {
-            if (p->profile) hipEventRecord(p->ev_last_b, p->stream3);
+            if (p->profile > 1) hipEventRecord(p->ev_last_b, p->stream3);
             HIPCHK(hipMemcpyAsync(&p->hb->c2, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream3));
             p->wait_b = p->stream3;
         }
     } else {
-        if (p->profile) hipEventRecord(p->ev_last, p->stream);
+        if (p->profile > 1) hipEventRecord(p->ev_last, p->stream);
         HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream));
     }
     p->fin = p->stream;       // copies of the records are issued here after the wait: ordered before the next image's kernels
@@ -1135,6 +1143,12 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     // the overflow flag may have been raised by either detection stream after the other took its snapshot
     int ovf = hc.overflow | p->hb->c.overflow | (p->wait_b ? p->hb->c2.overflow : 0);
     if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
+    if (p->profile == 1) {                   // light profile: running totals, read once by the caller's benchmark loop
+        float tot = 0, bms = 0; int32_t bl = 0; double px = 0;
+        if (siftmi_plan_last_kernel_ms(p, &tot, nullptr, nullptr, nullptr) == SIFTMI_OK && siftmi_plan_blur_ms(p, 0, &bms, &bl, &px) == SIFTMI_OK) {
+            p->acc_calls++; p->acc_total_ms += tot; p->acc_b0_ms += bms; p->acc_b0_launches += bl; p->acc_b0_pixels += px;
+        }
+    }
     p->last_count = n;
     p->last_group0 = hc.grp_out_end[p->bands_last ? p->bands_last - 1 : 0] - hc.grp_out_start[0];
     *n_out = n;
@@ -1579,14 +1593,28 @@ int siftmi_plan_last_kernel_ms(const siftmi_plan *p, float *total_ms, float *blu
                                double *blur_pixels) {
     if (!p) return fail(SIFTMI_EINVAL, "null plan");
     if (!p->profile) return fail(SIFTMI_EINVAL, "plan was created with profile=0");
-    float tot = 0;
-    HIPCHK(hipEventElapsedTime(&tot, p->ev_first, p->ev_last));
-    if (p->wait_b) {
-        float tb = 0;
-        if (hipEventElapsedTime(&tb, p->ev_first, p->ev_last_b) == hipSuccess && tb > tot) tot = tb;
+    float tot = 0;                            // light profile: not measured (0)
+    if (p->profile > 1) {
+        HIPCHK(hipEventElapsedTime(&tot, p->ev_first, p->ev_last));
+        if (p->wait_b) {
+            float tb = 0;
+            if (hipEventElapsedTime(&tb, p->ev_first, p->ev_last_b) == hipSuccess && tb > tot) tot = tb;
+        }
     }
     if (total_ms) *total_ms = tot;
     return siftmi_plan_blur_ms(p, -1, blur_ms, blur_launches, blur_pixels);
+}
+
+int siftmi_plan_profile_totals(siftmi_plan *p, int32_t reset, int64_t *calls, double *total_ms, double *blur0_ms,
+                               int64_t *blur0_launches, double *blur0_pixels) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (calls) *calls = p->acc_calls;
+    if (total_ms) *total_ms = p->acc_total_ms;
+    if (blur0_ms) *blur0_ms = p->acc_b0_ms;
+    if (blur0_launches) *blur0_launches = p->acc_b0_launches;
+    if (blur0_pixels) *blur0_pixels = p->acc_b0_pixels;
+    if (reset) { p->acc_calls = 0; p->acc_b0_launches = 0; p->acc_total_ms = p->acc_b0_ms = p->acc_b0_pixels = 0; }
+    return SIFTMI_OK;
 }
 
 int siftmi_plan_blur_ms(const siftmi_plan *p, int32_t octave, float *blur_ms, int32_t *blur_launches, double *blur_pixels) {

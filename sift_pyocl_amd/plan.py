@@ -357,6 +357,15 @@ class SiftPlan(object):
         out.update(blur0_ms=blur.value, blur0_launches=nl.value, blur0_pixels=px.value)
         return out
 
+    def profile_totals(self, reset=False):
+        """Running totals of ``kernel_times()`` over every call since the last reset (profile="light"): dict(calls,
+        total_ms, blur0_ms, blur0_launches, blur0_pixels).  A benchmark loop reads this once after its timed region."""
+        calls, nl = C.c_int64(), C.c_int64()
+        tot, b0, px = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().siftmi_plan_profile_totals(self._handle, int(bool(reset)), C.byref(calls), C.byref(tot), C.byref(b0),
+                                                         C.byref(nl), C.byref(px)))
+        return dict(calls=calls.value, total_ms=tot.value, blur0_ms=b0.value, blur0_launches=nl.value, blur0_pixels=px.value)
+
     def count_kp(self, output):
         """Print the number of keypoint per octave (plan.py:811-821): `output` = one (n, 4) array per octave,
         rows with column 1 == -1 are holes"""

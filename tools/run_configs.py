@@ -26,6 +26,7 @@ def run(size, kind, octaves, reps, device_input=True):
     src = torch.from_numpy(img).cuda() if device_input else img
     dt, k = timed(plan, src, reps)
     kt = plan.kernel_times()
+    if kt["total_ms"] <= 0: kt["total_ms"] = 1e3 * dt      # light profile: only the blur bracket is timed; the wall time stands in
     ba = bytes_alg(size, size, plan.octave_max, len(k))
     print("| %5d^2 %-6s | oct %d | %s | %9.3f ms | %8.0f Mpix/s | %9.0f kp/s | %7d kp | kernels %.3f ms | pipeline %.0f GB/s (%.1f %% of 8 TB/s) | blur oct0 %.0f GB/s |" % (
         size, kind, plan.octave_max, "device" if device_input else "host  ", 1e3 * dt, size * size / 1e6 / dt, len(k) / dt, len(k),

@@ -276,11 +276,19 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 distsq = distsq + dif * dif;
                 valid = (gval > 0.0f) && (distsq < lim);
                 if (valid) {
-                    const float a = siftmath::atan2f_fast(-gy, gx, fold);
+                    // the two Ziv candidates in one basic block (their binary64 chains interleave), one branch for both fall-backs
+                    const float earg = fast_div ? siftmath::div_by_reciprocal(-distsq, two_s2, r_two_s2) : -distsq / two_s2;
+                    bool ok_a, ok_e;
+                    float a = siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
+                    float ew = siftmath::expf_fast_try(earg, ok_e);
+                    if (!(ok_a && ok_e)) {
+                        if (!ok_a) a = siftmath::atan2f_(-gy, gx);
+                        if (!ok_e) ew = siftmath::expf_(earg);
+                    }
                     bin = (int)siftmath::div_by_reciprocal(36.0f * (a + SM_PI_F + 0.001f), 2.0f * SM_PI_F, 1.0f / (2.0f * SM_PI_F));
                     valid = (bin >= 0) && (bin <= 36);
                     bin = min(max(bin, 0), 35);
-                    val = siftmath::expf_fast(fast_div ? siftmath::div_by_reciprocal(-distsq, two_s2, r_two_s2) : -distsq / two_s2) * gval;
+                    val = ew * gval;
                 }
                 if (valid) atomicOr(reinterpret_cast<unsigned *>(L.mask) + 2 * bin + (lane >> 5), 1u << (lane & 31));
             }
@@ -291,6 +299,9 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             const int padded = (votes + 3) & ~3;
             const int seg = wave_prefix_incl(padded) - padded;
             if (lane < 36) L.mbase[lane] = (unsigned)seg;
+            // the last group of four of a segment starts as +0: its padding then adds +0 (an exact no-op on these non-negative
+            // sums) and the owners' loops need no per-element masks
+            if (votes) reinterpret_cast<float4 *>(L.pool)[(seg + padded - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
             __builtin_amdgcn_wave_barrier();
             // voters: value to segment base + rank among the voters of the same bin (mbcnt: set bits below this lane)
             {
@@ -304,10 +315,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 // owners: ordered sum of the segment
                 for (int k0 = 0; k0 < padded; k0 += 4) {
                     const float4 v = pool4[(seg + k0) >> 2];
-                    h = h + v.x;
-                    h = h + ((k0 + 1 < votes) ? v.y : 0.0f);
-                    h = h + ((k0 + 2 < votes) ? v.z : 0.0f);
-                    h = h + ((k0 + 3 < votes) ? v.w : 0.0f);
+                    h = h + v.x; h = h + v.y; h = h + v.z; h = h + v.w;
                 }
                 if (votes) L.mask[lane] = make_uint2(0u, 0u);
                 __builtin_amdgcn_wave_barrier();
@@ -322,10 +330,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                         const float4 *pq = reinterpret_cast<const float4 *>(lds_all[q].pool);
                         for (int k0 = 0; k0 < vq; k0 += 4) {
                             const float4 v = pq[(sq + k0) >> 2];
-                            h = h + v.x;
-                            h = h + ((k0 + 1 < vq) ? v.y : 0.0f);
-                            h = h + ((k0 + 2 < vq) ? v.z : 0.0f);
-                            h = h + ((k0 + 3 < vq) ? v.w : 0.0f);
+                            h = h + v.x; h = h + v.y; h = h + v.z; h = h + v.w;
                         }
                         if (vq) lds_all[q].mask[lane] = make_uint2(0u, 0u);
                     }

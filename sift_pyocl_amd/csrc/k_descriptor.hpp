@@ -71,6 +71,10 @@ __device__ __forceinline__ unsigned desc_lds_addr(const void *p) { return (unsig
 __device__ __forceinline__ void desc_pool_init(DescPool &P, int lane) {
     P.S[0][lane] = 0u; P.S[0][lane + 64] = 0u; P.S[1][lane] = 0u; P.S[1][lane + 64] = 0u;
     P.Sdummy[lane] = 0u;
+    // (the workgroup-per-keypoint form reads the entries of every wave's area each round: an area whose wave has had no
+    // batch yet -- a window of fewer than 256 samples -- must read as "no contributors")
+    *reinterpret_cast<uint4 *>(&P.ent[lane]) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(&P.ent[lane + 64]) = make_uint4(0u, 0u, 0u, 0u);
     if (lane == 0) *reinterpret_cast<uint4 *>(&P.ent[SIFT_DESC_DUMMY]) = make_uint4(~0u, ~0u, desc_lds_addr(&P.pool[960]), 0u);
     if (lane < 4) P.pool[896 + lane] = 0.0f;
 }

@@ -92,6 +92,34 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
         assert_same_keypoints(big.keypoints(img), got, "init_sigma %g, workgroup-per-keypoint form" % init_sigma)
 
 
+@pytest.mark.parametrize("shape", [(26, 26), (22, 40), (40, 21), (31, 64)])
+def test_clipped_windows_in_both_descriptor_forms(siftlib, oracle, shape):
+    """Frames barely larger than a descriptor window: every window is clipped by the frame, many hold fewer than 256
+    samples -- in the workgroup-per-keypoint form some waves then never get a batch, and their (never written) routing
+    tables must read as empty.  Both forms against the oracle, a small detection border so that keypoints sit at the edge;
+    several fresh plans, because what a never-written table holds is whatever the previous kernel left in LDS."""
+    import sift_pyocl_amd as sp
+    from sift_pyocl_amd.param import par
+    saved = dict(par)
+    try:
+        par.update(dict(BorderDist=2))
+        opar = oracle.default_params()
+        opar.border_dist = 2
+        found = 0
+        for seed in range(4):
+            img = smooth_noise(shape, seed=300 + seed, sigma=1.2)
+            want = oracle.keypoints(img, par=opar)
+            found += len(want)
+            for team in (1 << 30, 0):
+                plan = sp.SiftPlan(template=img)
+                plan.set_option("desc_team", team)
+                plan.set_option("ori_team", team)
+                assert_same_keypoints(plan.keypoints(img), want, "%r seed %d desc_team=%d" % (shape, seed, team))
+        assert found > 0
+    finally:
+        par.update(saved)
+
+
 def test_result_arrays_outlive_the_plan_and_recycle(siftlib):
     """Results are views of pinned blocks from the library's pool: they must stay valid after later calls and after the
     plan is gone, and dropping them must hand the blocks back (no growth over many calls)."""

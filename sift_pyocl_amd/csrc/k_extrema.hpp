@@ -21,11 +21,11 @@ struct BlurPlanes { const float *p[6]; };
 // One wave scans a strip 62 columns wide (lanes 0 and 63 are halo) and `rows` rows high.  A strip is a serial march
 // (one row of loads in flight ahead of the row being tested), so its height is the latency of the launch: 32 rows on
 // large planes, fewer where 32-row strips would leave most SIMDs without a wave (extrema_strip_rows).
-#define SIFT_EXT_ROWS 32
-inline int extrema_strip_rows(int W, int H, int border) {
+#define SIFT_EXT_ROWS 64
+inline int extrema_strip_rows(int W, int H, int border, int min_strips = 2000) {
     const int nx = (W - 2 * border + 61) / 62;
     int rows = SIFT_EXT_ROWS;
-    while (rows > 4 && (int64_t)nx * ((H - 2 * border + rows - 1) / rows) < 12288) rows >>= 1;   // measured: 4096^2 -> 16, 2048^2 and below -> 4
+    while (rows > 4 && (int64_t)nx * ((H - 2 * border + rows - 1) / rows) < min_strips) rows >>= 1;   // 2000: 4096^2 -> 64, 2048^2 -> 32, 1024^2 -> 8, below -> 4
     return rows;
 }
 

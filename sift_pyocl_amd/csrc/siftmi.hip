@@ -117,6 +117,10 @@ struct Options {
     int tail_pixels = SIFT_TAIL_MAX_PIXELS;   // largest plane (W * H) the tail kernel takes
     int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
+    int ext_strips = 2000;   // ... which halves the 64-row strips until at least this many of them cover the plane.  Round 2 used 12288 (16-row
+                             // strips on a 4096^2 plane): the march of a strip re-reads two halo rows, and many short strips are many
+                             // ramp-ups; interleaved A/B, whole call: 4096^2 0.835 (12288) / 0.823 (4000) / 0.809 (2000) / 0.817 ms (1000),
+                             // 2048^2 0.521 -> 0.511, 2048^2 smoothed 1.544 -> 1.517, small frames unchanged; the launch alone 94 -> 81-86 us
     int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
     int chain0 = 1;          // octave 0 end to end on the pyramid stream, later octaves' pyramids on the second chain
     int early_chain = 0;     // later octaves' chain starts when plane 3 of octave 0 exists (after its third blur), not after its fifth:
@@ -477,7 +481,7 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int band = -1
     const int border = p->par.border_dist;
     const int kcap = (int)p->kpsize;
     if (W > 2 * border && H > 2 * border) {
-        const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border);
+        const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border, p->opt.ext_strips);
         const int nx = (W - 2 * border + 61) / 62, ny_all = (H - 2 * border + rows - 1) / rows;
         int y_lo = -1, y_hi = -1, ny = ny_all;
         if (band >= 0) {                     // whole strips: band b takes strips [b * ny / B, (b + 1) * ny / B)
@@ -814,6 +818,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "bands") { if (v < 0 || v >= SIFT_GROUPS) return fail(SIFTMI_EINVAL, "bands must be in 0..%d", SIFT_GROUPS - 1); o.bands = v; }
     else if (n == "tile") o.tile = (int)v;
     else if (n == "ext_rows") o.ext_rows = (int)v;
+    else if (n == "ext_strips") { if (v < 1) return fail(SIFTMI_EINVAL, "ext_strips must be >= 1"); o.ext_strips = (int)v; }
     else if (n == "tail") o.tail = v != 0;
     else if (n == "tail_pixels") { if (v < 1 || v > SIFT_TAIL_MAX_PIXELS) return fail(SIFTMI_EINVAL, "tail_pixels must be in 1..%d", SIFT_TAIL_MAX_PIXELS); o.tail_pixels = (int)v; }
     else if (n == "early_pyr") o.early_pyr = v != 0;

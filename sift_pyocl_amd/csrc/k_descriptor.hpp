@@ -126,6 +126,7 @@ __device__ __forceinline__ float f32_neighbour(float x, bool up) {
 // what is the same for every sample of a keypoint's window (wave uniform)
 struct DescWindow {
     const float *I;            // blur[scale] of the keypoint's octave
+    const float *G, *O;        // MAPS forms: its gradient magnitude / orientation maps (OctaveTable::gmap / omap)
     unsigned W4;               // row pitch in bytes
     int W, H, irow, icol;
     float sine, cosine, drow, dcol, spacing, rspacing, angle;
@@ -136,14 +137,18 @@ struct DescWindow {
 // batch b + 1 are in flight while batch b is evaluated and accumulated (a wave runs its batches one after the other and
 // only four waves share a SIMD: what a wave does not overlap itself is not overlapped).
 struct DescSample { int ii, jj; float right, left, up, down; };
-template <bool INTERIOR>
+template <bool INTERIOR, bool MAPS>
 __device__ __forceinline__ void desc_fetch(const DescWindow &w, int ii, int jj, DescSample &q) {
     // loads address the plane as scalar base + 32-bit byte offset
     const int x = w.icol + jj, y = w.irow + ii;
     const unsigned off = __umul24((unsigned)y, w.W4) + ((unsigned)x << 2);   // planes hold <= 2^30 pixels, rows <= 2^22 bytes
     auto ld = [&](unsigned o) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(w.I) + o); };
     q.ii = ii; q.jj = jj;
-    if (INTERIOR) {
+    if (MAPS) {                 // (magnitude, orientation) of the sample, as compute_gradient_orientation left them
+        q.right = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(w.G) + off);
+        q.left = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(w.O) + off);
+        q.up = 0.0f; q.down = 0.0f;
+    } else if (INTERIOR) {
         q.right = ld(off + 4u); q.left = ld(off - 4u); q.up = ld(off - w.W4); q.down = ld(off + w.W4);
     } else {
         q.right = ld(x == w.W - 1 ? off : off + 4u); q.left = ld(x == 0 ? off : off - 4u);
@@ -156,7 +161,7 @@ __device__ __forceinline__ void desc_fetch(const DescWindow &w, int ii, int jj, 
 // the entry of the bin contribution n goes to, cval[n] its value; the dummies where the cell does not exist or the lane
 // is not `live`.
 // INTERIOR: the whole window lies at least one pixel inside the plane (no one-sided differences, image.cl:58-77).
-template <bool INTERIOR>
+template <bool INTERIOR, bool MAPS>
 __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample &q, bool live, const double *fold, const DescRoute &rt,
                                           unsigned (&tgs)[4], unsigned (&tgt)[8], float (&cval)[8]) {
     // ---- window coordinates (keypoints_cpu.cl:64-67): rx = ((cos*i - sin*j) - drow) / spacing + 1.5, cx likewise.
@@ -187,16 +192,16 @@ __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample 
         if ((x == 0) || (x == w.W - 1)) gx = 2.0f * gx;
         if ((y == 0) || (y == w.H - 1)) gy = 2.0f * gy;
     }
-    const float g = sqrtf(gx * gx + gy * gy);
+    const float g = MAPS ? q.right : sqrtf(gx * gx + gy * gy);
     const desc_f2 E = RC - (desc_f2){1.5f, 1.5f};
     const desc_f2 E2 = E * E;
     const float earg = -0.125f * (E2.x + E2.y);
     // the two Ziv candidates in one basic block (two independent binary64 chains side by side), one branch for both
-    bool ok_a, ok_e;
-    float o = siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
+    bool ok_a = true, ok_e;
+    float o = MAPS ? q.left : siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
     float ew = siftmath::expf_fast_try(earg, ok_e);
     if (!(ok_a && ok_e)) {                        // 2^-14 of the samples: the defining functions
-        if (!ok_a) o = siftmath::atan2f_(-gy, gx);
+        if (!MAPS && !ok_a) o = siftmath::atan2f_(-gy, gx);
         if (!ok_e) ew = siftmath::expf_(earg);
     }
     const float mag = g * ew;
@@ -337,11 +342,14 @@ __device__ __forceinline__ void desc_sum_pair(const float4 *pool4, int qa, int e
 }
 
 // per-keypoint set-up shared by the two forms: the window's constants from the oriented keypoint
+template <bool MAPS>
 __device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4 kq, int aux, DescWindow &w, int &R) {
     const int scale = aux & 0xff, oct = aux >> 8;
     w.W = tab.W[oct]; w.H = tab.H[oct];
     w.W4 = (unsigned)w.W * 4u;
     w.I = tab.base + tab.off[oct] + (size_t)scale * w.W * w.H;
+    w.G = MAPS ? tab.gmap + map_offset(tab, oct, scale) : nullptr;
+    w.O = MAPS ? tab.omap + map_offset(tab, oct, scale) : nullptr;
     const float foct = (float)(1 << oct);
     const float row = kq.y / foct, col = kq.x / foct;
     w.angle = kq.w;
@@ -357,6 +365,7 @@ __device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4
 // `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
 // after that it asks the counter, so that a wave with a small window does not idle while another still has two large
 // ones to go (windows differ by 4x in samples within an octave).
+template <bool MAPS>
 __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
                                                  int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
                                                  int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks) {
@@ -391,7 +400,7 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         }
         DescWindow w;
         int R;
-        desc_window(tab, kq, aux, w, R);
+        desc_window<MAPS>(tab, kq, aux, w, R);
         const int W = w.W, H = w.H, irow = w.irow, icol = w.icol;
         const float sine = w.sine, cosine = w.cosine, spacing = w.spacing, drow = w.drow, dcol = w.dcol;
         const int S = 2 * R + 1;
@@ -466,8 +475,8 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
             const int sc = min(s0 + lane, total - 1);
             while (sc >= L.row_start[rcur + 1]) rcur++;
             const int ii = rcur - R, jj = (int)L.row_jlo[rcur] + (sc - L.row_start[rcur]);
-            if (w.interior) desc_fetch<true>(w, ii, jj, nxt);
-            else desc_fetch<false>(w, ii, jj, nxt);
+            if (w.interior) desc_fetch<true, MAPS>(w, ii, jj, nxt);
+            else desc_fetch<false, MAPS>(w, ii, jj, nxt);
         };
         if (total > 0) fetch(0);
         for (int s0 = 0; s0 < total; s0 += 64) {
@@ -475,8 +484,8 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
             if (s0 + 64 < total) fetch(s0 + 64);     // wave uniform: the next batch's neighbours, in flight during this one
             unsigned tgs[4], tgt[8];
             float cval[8];
-            if (w.interior) desc_eval<true>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
-            else desc_eval<false>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
+            if (w.interior) desc_eval<true, MAPS>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
+            else desc_eval<false, MAPS>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
             int base_a, pa, pb;
             desc_route(L.P, rt, tgs, tgt, cval, lane, base_a, pa, pb);
             // ---- 3d. ordered sums of this lane's two bins
@@ -539,6 +548,7 @@ struct alignas(16) DescTeamLds {
     int blk_total[4];
 };
 
+template <bool MAPS>
 __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
                                                 int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
                                                 int host_capacity, DescTeamLds &T, double *fold) {
@@ -565,7 +575,7 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
         }
         DescWindow w;
         int R;
-        desc_window(tab, kq, aux, w, R);
+        desc_window<MAPS>(tab, kq, aux, w, R);
         const int W = w.W, H = w.H, irow = w.irow, icol = w.icol;
         const float sine = w.sine, cosine = w.cosine, spacing = w.spacing, drow = w.drow, dcol = w.dcol;
         const int S = 2 * R + 1;
@@ -643,8 +653,8 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
                     while (sc >= T.row_start[rcur + 1]) rcur++;
                     const int ii = rcur - R, jj = (int)T.row_jlo[rcur] + (sc - T.row_start[rcur]);
                     DescSample q;
-                    if (w.interior) { desc_fetch<true>(w, ii, jj, q); desc_eval<true>(w, q, s < total, fold, rt, tgs, tgt, cval); }
-                    else { desc_fetch<false>(w, ii, jj, q); desc_eval<false>(w, q, s < total, fold, rt, tgs, tgt, cval); }
+                    if (w.interior) { desc_fetch<true, MAPS>(w, ii, jj, q); desc_eval<true, MAPS>(w, q, s < total, fold, rt, tgs, tgt, cval); }
+                    else { desc_fetch<false, MAPS>(w, ii, jj, q); desc_eval<false, MAPS>(w, q, s < total, fold, rt, tgs, tgt, cval); }
                 }
                 int base_a, pa, pb;
                 desc_route(P, rt, tgs, tgt, cval, lane, base_a, pa, pb);
@@ -710,6 +720,7 @@ union DescLds {
     __device__ DescLds() {}
 };
 
+template <bool MAPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
@@ -719,7 +730,7 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
     __shared__ double fold[36];
     int start = range_start, end = range_end;
     if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
-    if (end - start < team_below) descriptor_team(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.team, fold);
+    if (end - start < team_below) descriptor_team<MAPS>(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.team, fold);
     else {
         // three workgroups per CU instead of four on a dense group: 154 k keypoints 5.56 -> 5.45 ms per call (the 9 k
         // keypoints of the headline frame prefer the full set: 0.903 against 0.927 ms)
@@ -729,7 +740,7 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
         const int count = end - start;
         const int nblocks = count >= 65536 ? min((int)gridDim.x, dense_blocks) : (count < 16384 ? min((int)gridDim.x, small_blocks) : (int)gridDim.x);
         if ((int)blockIdx.x >= nblocks) return;
-        descriptor_waves(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
+        descriptor_waves<MAPS>(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
                          (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr, nblocks);
     }
 }

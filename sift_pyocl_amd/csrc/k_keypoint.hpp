@@ -87,7 +87,14 @@ struct OctaveTable {
     const float *base;
     long long off[SIFT_MAX_OCTAVES];
     int W[SIFT_MAX_OCTAVES], H[SIFT_MAX_OCTAVES];
+    // Full gradient maps of the detection scales (planes 1..3) of every octave, for the MAPS forms of the per-keypoint
+    // kernels: magnitude / orientation of (octave o, plane s) start at off[o] / 2 + (s - 1) * W * H (three planes per
+    // octave where the pyramid has six).  Written by gradient_maps_kernel when the host expects a keypoint-rich frame.
+    const float *gmap, *omap;
 };
+__device__ __forceinline__ size_t map_offset(const OctaveTable &tab, int oct, int scale) {
+    return (size_t)(tab.off[oct] / 2) + (size_t)(scale - 1) * tab.W[oct] * tab.H[oct];
+}
 
 // Runs after the orientation kernel of group g: freezes the group's record range (the descriptor kernel of g
 // may then run while the next group appends) and opens the next group's ranges.
@@ -174,6 +181,10 @@ __device__ __forceinline__ int wave_prefix_incl(int x) {      // inclusive prefi
 // by the L2 (measured: 5.2 ns each), so an atomicAdd per keypoint made the counter the bottleneck of the kernel (half of
 // its time at 120 k keypoints).  A wave therefore parks its results in LDS and reserves slots for many keypoints at once;
 // at the end the four waves of a workgroup share a single atomicAdd.
+// MAPS: gradient magnitude / orientation come from the full maps (tab.gmap / tab.omap, same values: the same functions
+// wrote them) instead of four pixel loads, a square root and an arc tangent per sample -- a window sample of a dense frame
+// is evaluated by a dozen keypoints.
+template <bool MAPS>
 __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float ori_sigma,
                                                           const float4 *__restrict__ kp,
                                                           const int *__restrict__ kp_aux, Counters *cnt, int group,
@@ -230,6 +241,15 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
         if (!(k.y >= 0.0f)) continue;
         const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
+        const float *Gm = MAPS ? tab.gmap + map_offset(tab, oct, scale) : nullptr;
+        const float *Om = MAPS ? tab.omap + map_offset(tab, oct, scale) : nullptr;
+        auto taps_at = [&](int x, int y) {
+            if (!MAPS) return gradient_fetch(I, x, y, W, H);
+            GradTaps t = {};
+            const size_t pos = (size_t)y * W + x;
+            t.xa = Gm[pos]; t.xb = Om[pos];          // (magnitude, orientation)
+            return t;
+        };
         const int row = (int)((double)k.y + 0.5), col = (int)((double)k.z + 0.5);
         const float sigma = ori_sigma * k.w;
         const int radius = (int)((double)sigma * 3.0);
@@ -256,20 +276,20 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         int nr = 0, nc = 0;
         bool nvalid = locate(boff, nr, nc);
         GradTaps ntaps = {};
-        if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);   // the loads of batch b+1 are issued before batch b is evaluated
+        if (nvalid) ntaps = taps_at(nc, nr);   // the loads of batch b+1 are issued before batch b is evaluated
         for (int base = 0; base < total; base += bstep) {         // (workgroup uniform in team form)
             bool valid = nvalid;
             const int r = nr, c = nc;
             const GradTaps taps = ntaps;
             nvalid = locate(base + bstep + boff, nr, nc);
-            if (nvalid) ntaps = gradient_fetch(I, nc, nr, W, H);
+            if (nvalid) ntaps = taps_at(nc, nr);
             int bin = 0;
             float val = 0.0f;
             if (valid) {
                 float gx = taps.xa - taps.xb, gy = taps.ya - taps.yb;
                 if (taps.bx) gx = 2.0f * gx;
                 if (taps.by) gy = 2.0f * gy;
-                const float gval = sqrtf(gx * gx + gy * gy);
+                const float gval = MAPS ? taps.xa : sqrtf(gx * gx + gy * gy);
                 float dif = (float)r - k.y;
                 float distsq = dif * dif;
                 dif = (float)c - k.z;
@@ -278,11 +298,11 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 if (valid) {
                     // the two Ziv candidates in one basic block (their binary64 chains interleave), one branch for both fall-backs
                     const float earg = fast_div ? siftmath::div_by_reciprocal(-distsq, two_s2, r_two_s2) : -distsq / two_s2;
-                    bool ok_a, ok_e;
-                    float a = siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
+                    bool ok_a = true, ok_e;
+                    float a = MAPS ? taps.xb : siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
                     float ew = siftmath::expf_fast_try(earg, ok_e);
                     if (!(ok_a && ok_e)) {
-                        if (!ok_a) a = siftmath::atan2f_(-gy, gx);
+                        if (!MAPS && !ok_a) a = siftmath::atan2f_(-gy, gx);
                         if (!ok_e) ew = siftmath::expf_(earg);
                     }
                     bin = (int)siftmath::div_by_reciprocal(36.0f * (a + SM_PI_F + 0.001f), 2.0f * SM_PI_F, 1.0f / (2.0f * SM_PI_F));
@@ -648,6 +668,51 @@ __global__ void gradient_kernel(const float *__restrict__ img, float *__restrict
     gradient_at(img, x, y, W, H, g, o);
     grad[(size_t)y * W + x] = g;
     ori[(size_t)y * W + x] = o;
+}
+
+// Gradient maps of the three detection scales of the octaves [oct_lo, oct_hi): compute_gradient_orientation (image.cl:47-80)
+// as the reference runs it on blur[1..3] of every octave (plan.py:658-662).  A work item is a block of 256 columns x
+// SIFT_MAP_ROWS rows of one plane; workgroups walk the items of all the octaves with a grid stride (`total` of them, counted
+// by gradient_map_items on the host with the same formula).  The arc tangent takes the Ziv fast path of the per-keypoint
+// kernels, the defining function where it gives up: the same bits either way.
+#define SIFT_MAP_ROWS 32
+__host__ __device__ inline long long gradient_map_items_of(int W, int H) {
+    return 3LL * ((H + SIFT_MAP_ROWS - 1) / SIFT_MAP_ROWS) * ((W + 255) / 256);
+}
+__global__ __launch_bounds__(256) void gradient_maps_kernel(OctaveTable tab, int oct_lo, int oct_hi, long long total,
+                                                            float *__restrict__ gmap, float *__restrict__ omap) {
+    __shared__ double fold[36];
+    siftmath::load_atan_fold(fold);
+    __syncthreads();
+    for (long long item = blockIdx.x; item < total; item += gridDim.x) {      // workgroup uniform
+        long long rem = item;
+        int oct = oct_lo;
+        while (oct < oct_hi - 1 && rem >= gradient_map_items_of(tab.W[oct], tab.H[oct])) { rem -= gradient_map_items_of(tab.W[oct], tab.H[oct]); oct++; }
+        const int W = tab.W[oct], H = tab.H[oct];
+        const int nx = (W + 255) / 256, nyp = (H + SIFT_MAP_ROWS - 1) / SIFT_MAP_ROWS;
+        const int plane = (int)(rem / ((long long)nyp * nx));
+        const int r2 = (int)(rem - (long long)plane * nyp * nx);
+        const int cy = r2 / nx, xb = r2 - cy * nx;
+        if (plane > 2) continue;
+        const int x = xb * 256 + (int)threadIdx.x;
+        if (x >= W) continue;
+        const float *I = tab.base + tab.off[oct] + (size_t)(plane + 1) * W * H;
+        const size_t mo = map_offset(tab, oct, plane + 1);
+        const int y1 = min((cy + 1) * SIFT_MAP_ROWS, H);
+        // (independent rows: a march down the rows with the column's three pixels kept in registers -- three loads per pixel
+        // instead of four -- measured slower, 0.214 against 0.176 ms on a 4096^2 octave: its loads wait for one another)
+        for (int y = cy * SIFT_MAP_ROWS; y < y1; y++) {
+            const GradTaps t = gradient_fetch(I, x, y, W, H);
+            float gx = t.xa - t.xb, gy = t.ya - t.yb;
+            if (t.bx) gx = 2.0f * gx;
+            if (t.by) gy = 2.0f * gy;
+            bool ok;
+            float a = siftmath::atan2f_fast_try(-gy, gx, fold, ok);
+            if (!ok) a = siftmath::atan2f_(-gy, gx);
+            gmap[mo + (size_t)y * W + x] = sqrtf(gx * gx + gy * gy);
+            omap[mo + (size_t)y * W + x] = a;
+        }
+    }
 }
 
 // elementwise siftmath (test hook); fn 5 / 6: the Ziv fast paths of exp / atan2

@@ -106,6 +106,11 @@ struct Options {
     int desc_small_blocks = 576;   // ... and for groups of fewer than 16384 (the later octaves' chain needs the room)
     int desc_dense_blocks = 832;   // ... and for groups of >= 65536 keypoints (704: 5.47 ms per 154 k-keypoint call, 768-896: 5.27, 960: 5.31)
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
+    // Full gradient maps (gradient_maps_kernel) for the per-keypoint kernels: 0 never, 1 always, 2 when the previous image
+    // of this plan had at least one oriented keypoint per `maps_density` pixels in the group (octave 0 / the later octaves).
+    // Same records either way (tests/test_gpu_params.py); the maps pay from about one keypoint per 250 pixels (4096^2: 0.18 ms for octave 0 against 2.6 ns saved per keypoint).
+    int maps = 2, maps_density = 200;
+    int maps_blocks = 8192;  // workgroups of gradient_maps_kernel (grid stride over 256 x 32 pixel items)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
     int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
@@ -179,6 +184,12 @@ struct siftmi_plan {
     int raw_dtype = -1;           // dtype of the image currently staged in `raw` (-1: none)
     hipStream_t fin = nullptr;    // stream on which the last enqueued image ends
     int last_group0 = 0;          // oriented keypoints of octave 0 in the previous image (occupancy heuristic)
+    int last_group1 = 0;          // ... of the later octaves
+    float *gmap = nullptr, *omap = nullptr;   // gradient maps (allocated on first use: half the size of `planes` each)
+    size_t planes_floats = 0;
+    bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves
+    int later_group = 1;                      // group index of the later octaves in that image
+    hipEvent_t ev_maps0 = nullptr;
     hipEvent_t ev_join = nullptr;
     struct HostBack { Counters c, c2; } *hb = nullptr;   // pinned read-back blocks (one asynchronous D->H per ending stream)
     hipStream_t wait_a = nullptr, wait_b = nullptr;      // the stream(s) the image enqueued last ends on
@@ -460,6 +471,7 @@ OctaveTable octave_table(const siftmi_plan *p) {
     OctaveTable tab;
     memset(&tab, 0, sizeof tab);
     tab.base = p->planes;
+    tab.gmap = p->gmap; tab.omap = p->omap;
     for (int o = 0; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) {
         tab.off[o] = (long long)p->oct_off[(size_t)o];
         tab.W[o] = p->ow[(size_t)o];
@@ -585,9 +597,15 @@ void launch_orient_group(siftmi_plan *p, int group, hipStream_t st, bool banded)
         snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
         Scope sc(p, lab, false, 0, st);
         const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
-        hipLaunchKernelGGL(orientation_kernel, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                           (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
-                           banded ? 1 : 0, p->opt.ori_small_blocks);
+        const bool maps = group < p->later_group ? p->maps_g0 : p->maps_g1;
+        if (maps)
+            hipLaunchKernelGGL(orientation_kernel<true>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
+                               (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
+                               banded ? 1 : 0, p->opt.ori_small_blocks);
+        else
+            hipLaunchKernelGGL(orientation_kernel<false>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
+                               (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
+                               banded ? 1 : 0, p->opt.ori_small_blocks);
     }
     hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap, banded ? 0 : 1);
 }
@@ -611,11 +629,29 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
     if (p->desc_rows && !p->opt.desc_stream) {
         // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
         // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
-        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
+        const bool maps = group < p->later_group ? p->maps_g0 : p->maps_g1;
+        if (maps)
+            hipLaunchKernelGGL(descriptor_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
+        else
+            hipLaunchKernelGGL(descriptor_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
     } else
         hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                            (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
+}
+
+// gradient maps of the octaves [oct_lo, oct_hi) (their pyramids exist on `st`)
+void launch_gradient_maps(siftmi_plan *p, int oct_lo, int oct_hi, hipStream_t st) {
+    if (oct_lo >= oct_hi) return;
+    const OctaveTable tab = octave_table(p);
+    long long total = 0;
+    for (int o = oct_lo; o < oct_hi; o++) total += gradient_map_items_of(p->ow[(size_t)o], p->oh[(size_t)o]);
+    char lab[96];
+    snprintf(lab, sizeof lab, "gradient maps octaves %d-%d", oct_lo, oct_hi - 1);
+    Scope sc(p, lab, false, 0, st);
+    const unsigned blocks = (unsigned)std::min<long long>(total, p->opt.maps_blocks);
+    hipLaunchKernelGGL(gradient_maps_kernel, dim3(blocks), dim3(256), 0, st, tab, oct_lo, oct_hi, total, p->gmap, p->omap);
 }
 
 // orientation + descriptor for every refined keypoint of one group of octaves, on one stream; `mark_event`: recorded once
@@ -704,6 +740,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
         size_t off = 0;
         for (int o = 0; o < p->n_oct; o++) { p->oct_off.push_back(off); off += 6 * (size_t)p->ow[(size_t)o] * p->oh[(size_t)o]; }
         if (p->n_oct == 0) { p->oct_off.push_back(0); off = 6 * N; p->ow.assign(1, width); p->oh.assign(1, height); }
+        p->planes_floats = off;
         rc = p->alloc(&p->planes, off * sizeof(float));
     }
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
@@ -752,6 +789,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->ev_mark0) hipEventDestroy(p->ev_mark0);
     if (p->ev_p3) hipEventDestroy(p->ev_p3);
     if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
+    if (p->ev_maps0) hipEventDestroy(p->ev_maps0);
     if (p->ev_det) hipEventDestroy(p->ev_det);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
@@ -828,6 +866,9 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
     else if (n == "fused_shrink") o.fused_shrink = v != 0;
     else if (n == "fused_refine") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fused_refine must be 0, 1 or 2"); o.fused_refine = (int)v; }
+    else if (n == "maps") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "maps must be 0 (never), 1 (always) or 2 (by the previous image)"); o.maps = v; }
+    else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
+    else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
@@ -967,6 +1008,30 @@ int enqueue_body(siftmi_plan *p) {
     }
     p->bands_last = nbands;
     const int later = nbands ? nbands : 1;         // group index of the later octaves
+    // Gradient maps for the per-keypoint kernels of this image (option "maps"): large frames, by the previous image's counts
+    {
+        const int mode = p->opt.maps;
+        long long px0 = 0, px1 = 0;
+        for (int o = 0; o < p->n_oct; o++) {
+            const long long px = (long long)p->ow[(size_t)o] * p->oh[(size_t)o];
+            if (o == 0) px0 = px; else px1 += px;
+        }
+        auto dense = [&](int count, long long pixels) { return mode == 1 || (mode == 2 && (long long)count * p->opt.maps_density >= pixels); };
+        // (a frame whose octaves all go to the tail kernel has one group, the "later" one, holding octave 0 as well)
+        if (tail_first == 0) px1 += px0;
+        const bool layout_ok = mode != 0 && p->n_oct > 0 && (!two || chain0) && (mode == 1 || march_plane(p->ow[0], p->oh[0]));
+        bool want0 = layout_ok && tail_first != 0 && dense(p->last_group0, px0);
+        bool want1 = layout_ok && (p->n_oct > 1 || tail_first == 0) && dense(p->last_group1, px1);
+        if ((want0 || want1) && !p->gmap) {
+            // first keypoint-rich image of this plan: two maps of half the pyramid's size each (three planes per octave)
+            float *g = nullptr, *o = nullptr;
+            const size_t bytes = (p->planes_floats / 2 + 16) * sizeof(float);
+            if (p->alloc(&g, bytes) == SIFTMI_OK && p->alloc(&o, bytes) == SIFTMI_OK) { p->gmap = g; p->omap = o; p->bytes += 2 * (int64_t)bytes; }
+            else { want0 = want1 = false; (void)hipGetLastError(); }      // no room: the lazy forms
+        }
+        p->maps_g0 = want0; p->maps_g1 = want1; p->later_group = later;
+        if (want0 && two && !p->ev_maps0) HIPCHK(hipEventCreateWithFlags(&p->ev_maps0, hipEventDisableTiming));
+    }
     auto pyramid_stream = [&](int oct) { return (chain0 && oct > 0) ? p->stream3 : p->stream; };                                   // builds an octave's planes
     // Later octaves: the pyramid of octave o+1 needs only plane 3 of octave o, not its detection.  With "split_detect" the
     // extrema / refinement launches of octaves >= 1 go to `stream2` (idle in the chain0 layout), each behind the event
@@ -1045,12 +1110,21 @@ int enqueue_body(siftmi_plan *p) {
                 HIPCHK(hipEventRecord(p->ev_det, p->stream2));
                 HIPCHK(hipStreamWaitEvent(ts, p->ev_det, 0));
             }
+            if (p->maps_g1) launch_gradient_maps(p, tail_first == 0 ? 0 : 1, p->n_oct, ts);
             launch_describe_group(p, later, ts);
             if (two) HIPCHK(hipEventRecord(p->ev_grp1, ts));
             break;
         }
         int rc = build_pyramid(oct);
         if (rc) return rc;
+        if (oct == 0 && p->maps_g0) {
+            // octave 0's maps: on the idle stream beside detection and refinement (two-chain layout), else in line
+            if (two) {
+                HIPCHK(hipStreamWaitEvent(p->stream2, pyr0_done ? pyr0_done : p->ev_pyr[0], 0));
+                launch_gradient_maps(p, 0, 1, p->stream2);
+                HIPCHK(hipEventRecord(p->ev_maps0, p->stream2));
+            } else launch_gradient_maps(p, 0, 1, p->stream);
+        }
         // Option "early_pyr": octave 1's pyramid is enqueued before octave 0's detection and description (it needs only
         // ev_pyr[0]).  Off by default: the host is not what delays that chain.
         if (oct == 0 && chain0 && p->opt.early_pyr && p->n_oct > 1 && tail_first != 1 && (rc = build_pyramid(1))) return rc;
@@ -1058,6 +1132,7 @@ int enqueue_body(siftmi_plan *p) {
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
             if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, (oct == 0 && pyr0_done) ? pyr0_done : p->ev_pyr[(size_t)oct], 0));
         }
+        if (oct == 0 && p->maps_g0 && two && !nbands) HIPCHK(hipStreamWaitEvent(dst, p->ev_maps0, 0));     // (banded: the orientation launches follow the maps on stream2)
         if (oct == 0 && nbands) {
             for (int b = 0; b < nbands; b++) {
                 launch_detect_octave(p, 0, p->stream, b, nbands);
@@ -1079,6 +1154,7 @@ int enqueue_body(siftmi_plan *p) {
                 HIPCHK(hipEventRecord(p->ev_det, dst));
                 HIPCHK(hipStreamWaitEvent(ds, p->ev_det, 0));
             }
+            if (p->maps_g1) launch_gradient_maps(p, 1, p->n_oct, ds);
             launch_describe_group(p, later, ds);
             if (two) HIPCHK(hipEventRecord(p->ev_grp1, ds));
         }
@@ -1156,6 +1232,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     }
     p->last_count = n;
     p->last_group0 = hc.grp_out_end[p->bands_last ? p->bands_last - 1 : 0] - hc.grp_out_start[0];
+    p->last_group1 = (int)n - p->last_group0;
     *n_out = n;
     if (overflow) *overflow = ovf;
     return SIFTMI_OK;
@@ -2056,7 +2133,7 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     std::vector<int32_t> aux((size_t)n);
     for (int64_t i = 0; i < n; i++) aux[(size_t)i] = kp_scale[i] | (oct << 8);
     HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(orientation_kernel, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
+    hipLaunchKernelGGL(orientation_kernel<false>, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
                        par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
                        o.as<float4>(), oa.as<int>(), (int)capacity, 0, 0, 512);
     if ((rc = stage_end())) return rc;
@@ -2095,7 +2172,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
             if (!((int)((1.414f * spacing * 2.5f) + 0.5f) <= SIFT_DESC_MAXRAD)) block_ok = false;
         }
         if (block_ok)
-            hipLaunchKernelGGL(descriptor_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
+            hipLaunchKernelGGL(descriptor_kernel<false>, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
                                (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30);
         else

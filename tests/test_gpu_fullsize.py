@@ -38,7 +38,14 @@ def test_golden_digests_of_large_images(siftlib, name):
     maker, shape, kw = digest_cases()[name]
     img = maker(shape, **kw)
     golden = json.load(open(os.path.join(GOLD, "kp_digests.json")))[name]
-    assert kp_digest(sp.SiftPlan(template=img).keypoints(img)) == golden
+    plan = sp.SiftPlan(template=img)
+    assert kp_digest(plan.keypoints(img)) == golden
+    # the second call of a plan on a keypoint-rich frame switches to full gradient maps by itself (option "maps" = 2);
+    # forced on and off as well: same bytes
+    assert kp_digest(plan.keypoints(img)) == golden
+    for maps in (1, 0):
+        plan.set_option("maps", maps)
+        assert kp_digest(plan.keypoints(img)) == golden, "maps=%d" % maps
 
 
 def test_4096_white_noise_bit_exact(siftlib, oracle):

@@ -78,6 +78,19 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
     plan.set_option("ori_team", 0)
     assert_same_keypoints(plan.keypoints(img), want, "orientation: wave per keypoint for every group")
     plan.set_option("ori_team", 1024)
+    # full gradient maps instead of the lazy gradient ("maps": 1 always, 0 never, 2 by the previous image), every form
+    plan.set_option("maps", 1)
+    assert_same_keypoints(plan.keypoints(img), want, "gradient maps")
+    for team in (1 << 30, 0):
+        plan.set_option("desc_team", team)
+        plan.set_option("ori_team", team)
+        assert_same_keypoints(plan.keypoints(img), want, "gradient maps, team option %d" % team)
+    plan.set_option("desc_team", 1024)
+    plan.set_option("ori_team", 1024)
+    plan.set_option("overlap", 0)
+    assert_same_keypoints(plan.keypoints(img), want, "gradient maps, one stream")
+    plan.set_option("overlap", 1)
+    plan.set_option("maps", 2)
     plan.pinned_results = False                                  # plain numpy result + device-to-host copy
     assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
     for init_sigma in (3.0, 4.0):
@@ -111,10 +124,12 @@ def test_clipped_windows_in_both_descriptor_forms(siftlib, oracle, shape):
             want = oracle.keypoints(img, par=opar)
             found += len(want)
             for team in (1 << 30, 0):
-                plan = sp.SiftPlan(template=img)
-                plan.set_option("desc_team", team)
-                plan.set_option("ori_team", team)
-                assert_same_keypoints(plan.keypoints(img), want, "%r seed %d desc_team=%d" % (shape, seed, team))
+                for maps in (0, 1):
+                    plan = sp.SiftPlan(template=img)
+                    plan.set_option("desc_team", team)
+                    plan.set_option("ori_team", team)
+                    plan.set_option("maps", maps)
+                    assert_same_keypoints(plan.keypoints(img), want, "%r seed %d desc_team=%d maps=%d" % (shape, seed, team, maps))
         assert found > 0
     finally:
         par.update(saved)

@@ -71,9 +71,21 @@ def test_4096_white_noise_bit_exact(siftlib, oracle):
 def test_2048_keypoint_rich_bit_exact(siftlib, oracle):
     import sift_pyocl_amd as sp
     img = smooth_noise((2048, 2048), seed=3)
-    got = sp.SiftPlan(template=img).keypoints(img)
+    plan = sp.SiftPlan(template=img)
+    got = plan.keypoints(img)
     assert len(got) > 30000
-    assert_same_keypoints(got, oracle.keypoints(img), "2048 smoothed noise")
+    want = oracle.keypoints(img)
+    assert_same_keypoints(got, want, "2048 smoothed noise")
+    # launch-layout options that only large frames reach (none may change a byte): the band pipeline of octave 0, the early
+    # start of the later octaves' chain, detection on its own stream -- each with the lazy gradient and with full maps
+    for opts in (dict(bands=4), dict(bands=2, early_chain=1), dict(early_chain=1), dict(split_detect=1), dict(early_pyr=1), dict(chain0=0)):
+        for maps in (0, 1):
+            p2 = sp.SiftPlan(template=img)
+            p2.set_option("maps", maps)
+            for k, v in opts.items():
+                p2.set_option(k, v)
+            assert_same_keypoints(p2.keypoints(img), want, "2048 smoothed noise, %r maps=%d" % (opts, maps))
+            assert_same_keypoints(p2.keypoints(img), want, "2048 smoothed noise, %r maps=%d, second call" % (opts, maps))
 
 
 def test_odd_sizes_and_borders(siftlib, oracle):

@@ -18,8 +18,11 @@ for it in range(n):
     if dt != np.float32:
         img = ((img - img.min()) / (img.max() - img.min()) * np.iinfo(dt).max).astype(dt)
     want = pyoracle.keypoints(img.astype(np.float32))
-    got = sp.SiftPlan(template=img).keypoints(img)
+    plan = sp.SiftPlan(template=img)
+    got = plan.keypoints(img)
     assert_same_keypoints(got, want, "fuzz %d %dx%d %s" % (it, H, W, np.dtype(dt).name))
+    plan.set_option("maps", 1)                        # full gradient maps, whatever the density
+    assert_same_keypoints(plan.keypoints(img), want, "fuzz %d %dx%d %s, gradient maps" % (it, H, W, np.dtype(dt).name))
     if it % 7 == 0:
         bp = sp.BatchPlan(template=img, lanes=2)
         for g in bp.keypoints_batch([img, img]):

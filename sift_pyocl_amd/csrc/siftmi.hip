@@ -631,8 +631,9 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
         // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
         const bool maps = group < p->later_group ? p->maps_g0 : p->maps_g1;
         if (maps)
+            // (the MAPS form of a dense group wants every workgroup of the launch: 154 k keypoints 4.68 ms at 832, 4.48 at 960)
             hipLaunchKernelGGL(descriptor_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks);
         else
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                                (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(SIFT_TAIL_THREADS) __attribute__((amdgpu_waves_per_
             default: tail_blur<27>(P, A, T, o.plane[s + 1], W, H, a.taps[s]); break;
         }
         if (s == 2 && k + 1 < a.n) {   // plane 3 is stored: release it to the next octave's workgroup
-            __threadfence();
+            // ONE agent-scope release, by the thread that raises the flag, behind the workgroup barrier (which orders every
+            // wave's stores before it): a device-scope release writes the XCD's L2 back, and one per wave is fifteen too many
             __syncthreads();
             if (tid == 0) __hip_atomic_store(ready + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -368,7 +368,8 @@ __device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4
 template <bool MAPS>
 __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
                                                  int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
-                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks) {
+                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks,
+                                                 const int *__restrict__ order) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
     siftmath::load_atan_fold(fold);
@@ -384,7 +385,9 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         if (lane == 0) t = atomicAdd(next, 1);
         return start + nwaves + __builtin_amdgcn_readfirstlane(t);
     };
-    for (int i = start + gwave; i < end; i = advance(i)) {
+    for (int t = start + gwave; t < end; t = advance(t)) {
+        // hand-out position t -> keypoint i: list order, or the order mark_group_kernel prepared (largest windows first)
+        const int i = order ? __builtin_amdgcn_readfirstlane(order[t]) : t;
         // the keypoint is the same in every lane: keep its integer attributes in scalar registers
         float4 kq = okp[i];              // (x, y, sigma*oct, angle)
         kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_W
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
                        int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
-                       int team_below, int dynamic, int dense_blocks, int small_blocks) {
+                       int team_below, int dynamic, int dense_blocks, int small_blocks, const int *__restrict__ order) {
     __shared__ DescLds lds;
     __shared__ double fold[36];
     int start = range_start, end = range_end;
@@ -741,7 +744,8 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
         const int nblocks = count >= 65536 ? min((int)gridDim.x, dense_blocks) : (count < 16384 ? min((int)gridDim.x, small_blocks) : (int)gridDim.x);
         if ((int)blockIdx.x >= nblocks) return;
         descriptor_waves<MAPS>(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
-                         (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr, nblocks);
+                         (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr, nblocks,
+                         (cnt && order && cnt->grp_sorted[group]) ? order : nullptr);
     }
 }
 

@@ -80,6 +80,7 @@ struct Counters {
     uint32_t mm[2];                     // order-encoded min / max of the input (k_pyramid.hpp), read back with the counters
     int tail_ready[8];                  // octave_tail_kernel: plane 3 of tail octave k is in HBM (k_tail.hpp)
     int desc_next[SIFT_GROUPS + 1];     // descriptor_kernel: keypoints of the group handed out beyond every wave's first one
+    int grp_sorted[SIFT_GROUPS + 1];    // mark_group_kernel wrote the group's hand-out order (largest windows first) to the order array
 };
 
 // where the six planes of every octave live: plane(o, s) = base + off[o] + s * W[o] * H[o]
@@ -100,11 +101,56 @@ __device__ __forceinline__ size_t map_offset(const OctaveTable &tab, int oct, in
 // may then run while the next group appends) and opens the next group's ranges.
 // `kp_too`: also open the next group's refined-list range here (groups whose refinement waits for this kernel); banded
 // groups have had it opened by mark_kp_kernel already.
-__global__ void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_capacity, int kp_too) {
-    const int kp_end = min(c->n_kp, kp_capacity), out_end = min(c->n_out, out_capacity);
-    c->grp_out_end[g] = out_end;
-    if (kp_too) c->grp_kp_start[g + 1] = kp_end;
-    c->grp_out_start[g + 1] = out_end;
+// It also orders the group for the descriptor launch (groups of at most `sort_below` keypoints): `order[start .. end)` lists
+// the group's oriented keypoints by descending window size (counting sort over 16 classes of sigma in octave pixels).  The
+// descriptor kernel hands keypoints out through a counter; a window has 17 to 75 batches of samples, and in list order the
+// launch ends with whatever large windows were handed out last on an otherwise idle chip.  Records keep their positions:
+// only the order of processing changes.
+#define SIFT_MARK_THREADS 1024
+#define SIFT_MARK_PER_THREAD 16               // groups of up to 16384 keypoints are ordered
+__global__ __launch_bounds__(SIFT_MARK_THREADS) void mark_group_kernel(Counters *c, int g, int kp_capacity, int out_capacity, int kp_too,
+                                                                        const float4 *__restrict__ okp, const int *__restrict__ oaux,
+                                                                        int *__restrict__ order, int sort_above, int sort_below) {
+    __shared__ int s_start, s_end, hist[16], offs[16];
+    if (threadIdx.x == 0) {
+        const int kp_end = min(c->n_kp, kp_capacity), out_end = min(c->n_out, out_capacity);
+        c->grp_out_end[g] = out_end;
+        if (kp_too) c->grp_kp_start[g + 1] = kp_end;
+        c->grp_out_start[g + 1] = out_end;
+        s_start = c->grp_out_start[g]; s_end = out_end;
+    }
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int start = s_start, n = s_end - s_start;
+    // (workgroup uniform) list order for groups the workgroup-per-keypoint form takes, and for large ones
+    if (!order || n < sort_above || n > sort_below || n > SIFT_MARK_THREADS * SIFT_MARK_PER_THREAD) return;
+    // every thread's keypoints in one round of loads (a loop of dependent loads made this kernel cost more than it saved)
+    unsigned long long classes = 0ull;                         // 4 bits per element
+#pragma unroll
+    for (int k = 0; k < SIFT_MARK_PER_THREAD; k++) {
+        const int i = k * SIFT_MARK_THREADS + (int)threadIdx.x;
+        if (i < n) {
+            const float sig = okp[start + i].z;
+            const int aux = oaux[start + i];
+            const float so = sig / (float)(1 << (aux >> 8));   // sigma in pixels of the keypoint's octave (1.4 .. 3.8 by default)
+            classes |= (unsigned long long)min(max((int)((so - 1.0f) * 5.0f), 0), 15) << (4 * k);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SIFT_MARK_PER_THREAD; k++)
+        if (k * SIFT_MARK_THREADS + (int)threadIdx.x < n) atomicAdd(&hist[(classes >> (4 * k)) & 15], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 15; b >= 0; b--) { offs[b] = run; run += hist[b]; }
+        c->grp_sorted[g] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SIFT_MARK_PER_THREAD; k++) {
+        const int i = k * SIFT_MARK_THREADS + (int)threadIdx.x;
+        if (i < n) order[start + atomicAdd(&offs[(classes >> (4 * k)) & 15], 1)] = start + i;
+    }
 }
 
 // Runs after the refinement of band g of octave 0: freezes the band's refined-list range (its orientation pass may then
@@ -119,7 +165,7 @@ __global__ void mark_kp_kernel(Counters *c, int g, int kp_capacity, int oct, int
 __global__ void begin_image_kernel(Counters *c) {
     const int t = threadIdx.x;
     if (t == 0) { c->n_out = 0; c->overflow = 0; c->n_kp = 0; c->tail_timeout = 0; c->mm[0] = 0xffffffffu; c->mm[1] = 0u; }
-    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_kp_end[t] = 0; c->grp_cand_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; c->desc_next[t] = 0; }
+    if (t <= SIFT_GROUPS) { c->grp_kp_start[t] = 0; c->grp_kp_end[t] = 0; c->grp_cand_start[t] = 0; c->grp_out_start[t] = 0; c->grp_out_end[t] = 0; c->desc_next[t] = 0; c->grp_sorted[t] = 0; }
     if (t < SIFT_MAX_OCTAVES) c->n_cand[t] = 0;
     if (t < 8) c->tail_ready[t] = 0;
 }

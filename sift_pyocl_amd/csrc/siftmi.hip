@@ -113,6 +113,8 @@ struct Options {
     int maps_blocks = 8192;  // workgroups of gradient_maps_kernel (grid stride over 256 x 32 pixel items)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
+    int desc_sort = 16384;   // groups of at most this many oriented keypoints (<= 16384) are described largest window first (0: list order)
+    int desc_sort_density = 600;   // ... and only with fewer keypoints than one per this many pixels of octave 0
     int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
     int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)
     int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
@@ -135,7 +137,7 @@ struct Options {
                              // quarter of the keypoints lasts as long as its slowest keypoint (~120 us with a wave per keypoint), the bands'
                              // descriptor launches run one after the other, and the small detection / orientation launches each pay their
                              // ramp: the serial phases are cheaper than the pipeline.  Kept for experiments, off.
-    int ori_small_blocks = 512;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints
+    int ori_small_blocks = 608;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints (512 until the descriptor launch was ordered: 0.809 ms; 576-640: 0.799-0.801; 704: 0.813)
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
 };
@@ -206,6 +208,7 @@ struct siftmi_plan {
     int *kp_scale = nullptr;
     float4 *okp = nullptr;
     int *oaux = nullptr;
+    int *order = nullptr;         // hand-out order of the descriptor launch (mark_group_kernel), indices into okp
     KpRecord *records = nullptr;
     KpRecord *host_out = nullptr; // pinned result array of the call being enqueued (zero-copy delivery), or null
     int host_cap = 0;
@@ -607,7 +610,16 @@ void launch_orient_group(siftmi_plan *p, int group, hipStream_t st, bool banded)
                                (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
                                banded ? 1 : 0, p->opt.ori_small_blocks);
     }
-    hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(1), 0, st, p->cnt, group, kcap, kcap, banded ? 0 : 1);
+    // Octave 0 of a frame with few keypoints per pixel is described largest window first (mark_group_kernel orders the
+    // hand-out; k_keypoint.hpp).  Measured: headline frame -2.1 %, 2048^2 white noise -1.2 %; on keypoint-rich frames the
+    // list order wins (neighbours in the list are neighbours in the image and share their window pixels in the caches:
+    // 1024^2 smoothed noise +5 % when ordered), hence the bound of one keypoint per `desc_sort_density` pixels; the later
+    // octaves' groups +-0.
+    const bool octave0 = group < p->later_group && p->n_oct > 0;
+    const long long px0 = p->n_oct > 0 ? (long long)p->ow[0] * p->oh[0] : 0;
+    const int sort_below = (p->opt.desc_sort > 0 && octave0) ? (int)std::min<long long>(p->opt.desc_sort, px0 / std::max(1, p->opt.desc_sort_density)) : 0;
+    hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(SIFT_MARK_THREADS), 0, st, p->cnt, group, kcap, kcap, banded ? 0 : 1,
+                       (const float4 *)p->okp, (const int *)p->oaux, sort_below > 0 ? p->order : nullptr, std::max(2, p->opt.desc_team), sort_below);
 }
 
 // descriptors of one group's oriented keypoints
@@ -633,10 +645,10 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
         if (maps)
             // (the MAPS form of a dense group wants every workgroup of the launch: 154 k keypoints 4.68 ms at 832, 4.48 at 960)
             hipLaunchKernelGGL(descriptor_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks);
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks, (const int *)p->order);
         else
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
+                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks, (const int *)p->order);
     } else
         hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                            (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
@@ -769,6 +781,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc) rc = p->alloc(&p->kp_scale, (size_t)p->kpsize * sizeof(int));
     if (!rc) rc = p->alloc(&p->okp, (size_t)p->kpsize * sizeof(float4));
     if (!rc) rc = p->alloc(&p->oaux, (size_t)p->kpsize * sizeof(int));
+    if (!rc) rc = p->alloc(&p->order, (size_t)p->kpsize * sizeof(int));
     if (!rc) rc = p->alloc(&p->records, (size_t)p->kpsize * sizeof(KpRecord));
     if (!rc) rc = compute_schedule(p);
     if (!rc && hipMemset(p->cnt, 0, sizeof(Counters)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipMemset failed");
@@ -870,6 +883,8 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "maps") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "maps must be 0 (never), 1 (always) or 2 (by the previous image)"); o.maps = v; }
     else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
     else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
+    else if (n == "desc_sort_density") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_sort_density must be >= 1"); o.desc_sort_density = v; }
+    else if (n == "desc_sort") { if (v < 0) return fail(SIFTMI_EINVAL, "desc_sort must be >= 0"); o.desc_sort = v; }
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
@@ -2175,7 +2190,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
         if (block_ok)
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30);
+                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30, (const int *)nullptr);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,

@@ -91,6 +91,15 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
     assert_same_keypoints(plan.keypoints(img), want, "gradient maps, one stream")
     plan.set_option("overlap", 1)
     plan.set_option("maps", 2)
+    # the descriptor launch in list order / largest windows first whatever the density ("desc_sort", "desc_sort_density")
+    for sort, density in ((0, 600), (16384, 1)):
+        plan.set_option("desc_sort", sort)
+        plan.set_option("desc_sort_density", density)
+        plan.set_option("desc_team", 0)                          # the wave-per-keypoint form is the one that follows the order
+        assert_same_keypoints(plan.keypoints(img), want, "desc_sort %d" % sort)
+    plan.set_option("desc_sort", 16384)
+    plan.set_option("desc_sort_density", 600)
+    plan.set_option("desc_team", 1024)
     plan.pinned_results = False                                  # plain numpy result + device-to-host copy
     assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
     for init_sigma in (3.0, 4.0):

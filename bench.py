@@ -136,6 +136,120 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+# ---- VALU roofline (round 4).  Issue intervals per wave-instruction and SIMD, measured on this chip with
+# tools/ubench/valu_rate.hip (profiles/r04/valu_issue_rate.txt; 8 waves per SIMD, 8 independent chains, shader clock read
+# beside it): plain f32 add / mul / fma and u32 add / sub / logic / right shifts / v_mov 2.4 cycles; every other class
+# (packed f32, f64, conversions, compares, selects, left shifts, 3-operand integer ops, DPP, mbcnt, v_sad) 4.2; f32
+# transcendentals 8.2, f64 ones 16.2.  The hardware guide's "2 cycles per wave64 op" holds for the first class only.
+VALU_SIMDS = 1024
+VALU_CLOCK_GHZ = 2.3          # shader clock the ubench reads under VALU load (2.1-2.4)
+VALU_CYCLES = {"f32": 2.4, "f32_packed": 4.2, "f64": 4.2, "trans_f32": 8.2, "trans_f64": 16.2, "cvt": 4.2, "int32": 3.3, "int64": 4.3, "other": 3.3}
+
+
+def roofline_valu(ms_per_step):
+    """Issue time of one headline frame's VALU instructions (committed PMC counts x measured issue intervals) against the
+    measured time of a step.  `frac` = the share of a step during which every SIMD of the chip would have to issue VALU
+    instructions back to back; the counts are replayed from the committed file, not observed in this run."""
+    rel = "profiles/r04/valu_frame.json"
+    try:
+        vf = json.load(open(os.path.join(ROOT, rel)))
+    except Exception:
+        return None
+    cycles = 0.0
+    instr = 0.0
+    for fam, d in vf["families"].items():
+        c = d["classes"]
+        f32 = c["ADD_F32"] + c["MUL_F32"] + c["FMA_F32"]
+        packed = fam.startswith("blur")          # the blur kernels do their arithmetic in v_pk_mul_f32 / v_pk_add_f32
+        cycles += f32 * VALU_CYCLES["f32_packed" if packed else "f32"]
+        cycles += (c["ADD_F64"] + c["MUL_F64"] + c["FMA_F64"]) * VALU_CYCLES["f64"]
+        cycles += c["TRANS_F32"] * VALU_CYCLES["trans_f32"] + c["TRANS_F64"] * VALU_CYCLES["trans_f64"]
+        cycles += c["CVT"] * VALU_CYCLES["cvt"] + c["INT32"] * VALU_CYCLES["int32"] + c["INT64"] * VALU_CYCLES["int64"]
+        cycles += max(d["other"], 0.0) * VALU_CYCLES["other"]
+        instr += d["valu"]
+    if instr <= 0 or ms_per_step <= 0:
+        return None
+    issue_ms = cycles / (VALU_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3
+    mean_cycles = cycles / instr
+    peak = VALU_SIMDS * VALU_CLOCK_GHZ / mean_cycles                   # G wave-instructions / s at this frame's class mix
+    achieved = instr / 1e9 / (ms_per_step / 1e3)
+    return {"bound": "valu", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(achieved / peak, 4),
+            "instr_per_frame": round(instr), "mean_issue_cycles": round(mean_cycles, 2), "issue_ms_per_frame": round(issue_ms, 4),
+            "issue_ms_if_all_full_rate": round(instr * 2.4 / (VALU_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3, 4),
+            "issue_ms_if_all_half_rate": round(instr * 4.2 / (VALU_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3, 4),
+            "simds": VALU_SIMDS, "clock_ghz": VALU_CLOCK_GHZ, "cycles_per_class": VALU_CYCLES,
+            "source": "instruction counts replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU* of this command, tools/valu_frame.sh); "
+                      "issue intervals from profiles/r04/valu_issue_rate.txt (tools/ubench/valu_rate.hip)" % rel}
+
+
+def leg_c3(sp, torch, local_rank, size=16384, steps=3):
+    """C3: one 16384^2 frame, all octaves, resident in HBM; its own blur and whole-call rooflines (N = 1 extras leg)."""
+    plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, device=local_rank, profile="light")
+    t = torch.from_numpy(make_image(0, size)).cuda()
+    for _ in range(2):
+        kp = plan.keypoints(t)
+    plan.profile_totals(reset=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    nk = 0
+    for _ in range(steps):
+        nk += len(plan.keypoints(t))
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t1) / steps
+    tot = plan.profile_totals(reset=True)
+    n_oct = int(plan.octave_max)
+    blur_gbs = (8.0 * tot["blur0_pixels"] / 1e9) / (tot["blur0_ms"] / 1e3) if tot["blur0_ms"] > 0 else 0.0
+    balg = bytes_alg(size, size, n_oct, nk / steps)
+    del plan, t
+    torch.cuda.empty_cache()
+    return {"ms_per_image": round(1e3 * el, 3), "value": round(size * size / 1e6 / el, 1), "unit": "Mpix/s", "steps": steps,
+            "octaves": n_oct, "keypoints": int(nk / steps), "keypoints_per_s": round(nk / steps / el, 1),
+            "roofline": {"bound": "hbm", "kernel": "blur_team_kernel: the 6 full-resolution launches per image (1 GiB planes)",
+                         "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
+                         "avg_launch_us": round(1e3 * tot["blur0_ms"] / max(tot["blur0_launches"], 1), 1),
+                         "alg_bytes_per_launch": 8.0 * size * size, "traffic": None},
+            "roofline_pipeline": {"bound": "hbm", "achieved": round(balg / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(balg / el / 1e9 / HBM_PEAK_GBS, 4), "bytes_alg_per_image": balg},
+            "workload": "SiftPlan %dx%d fp32 uniform white noise, all %d octaves x 3 scales, input resident in HBM, records returned to host"
+                        % (size, size, n_oct)}
+
+
+def leg_c4(sp, torch, local_rank, steps=3):
+    """C4 on one GPU: the 64 x 2048^2 batch through a BatchPlan (16 lanes), records left in HBM as the exchange wants them."""
+    frames = [torch.from_numpy(make_image(1000 + i, C4_SIZE)).cuda() for i in range(C4_FRAMES)]
+    bp = sp.BatchPlan(shape=(C4_SIZE, C4_SIZE), dtype=np.float32, device=local_rank, profile="light")
+    n_oct = int(bp.octave_max)
+    for _ in range(2):
+        counts, rec = bp.keypoints_batch_device(frames)
+    torch.cuda.synchronize()
+    times, blur = [], None
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        counts, rec = bp.keypoints_batch_device(frames)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t1)
+        blur = bp.blur_times()
+    el = sorted(times)[len(times) // 2]
+    nk = int(sum(counts))
+    balg = C4_FRAMES * bytes_alg(C4_SIZE, C4_SIZE, n_oct, nk / C4_FRAMES)
+    blur_gbs = (8.0 * blur["blur0_pixels"] / 1e9) / (blur["blur0_ms"] / 1e3) if blur and blur["blur0_ms"] > 0 else 0.0
+    lanes = bp.lanes
+    del bp, frames
+    torch.cuda.empty_cache()
+    return {"ms_per_batch": round(1e3 * el, 3), "ms_per_frame": round(1e3 * el / C4_FRAMES, 4),
+            "value": round(C4_FRAMES * C4_SIZE * C4_SIZE / 1e6 / el, 1), "unit": "Mpix/s", "frames": C4_FRAMES, "lanes": lanes,
+            "octaves": n_oct, "keypoints": nk, "keypoints_per_s": round(nk / el, 1),
+            "roofline": {"bound": "hbm", "kernel": "the full-resolution (2048^2) blur launches of the batch; lanes overlap, so the "
+                                                   "bracket of a launch group also holds other lanes' kernels",
+                         "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None},
+            "roofline_pipeline": {"bound": "hbm", "achieved": round(balg / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(balg / el / 1e9 / HBM_PEAK_GBS, 4), "bytes_alg_per_batch": balg},
+            "workload": "batch of %d frames of %dx%d fp32 white noise on ONE GPU (BASELINE configs[3] without the other 7 GPUs), "
+                        "BatchPlan with %d lanes, frames resident in HBM, records left in HBM (keypoints_batch_device)"
+                        % (C4_FRAMES, C4_SIZE, C4_SIZE, lanes)}
+
+
 def extras(sp, torch, size, n_oct, local_rank):
     """Measurements beside the headline, N = 1 only, outside the timed region and never part of `value`."""
     out = {}
@@ -201,6 +315,44 @@ def extras(sp, torch, size, n_oct, local_rank):
         del plan, t
     except Exception as exc:
         out["keypoint_rich"] = {"error": str(exc)[:200]}
+    # (2c) the host-frame pipeline at the headline size: the reference API takes host numpy frames (plan.py:450-456); a
+    #      BatchPlan uploads frame i+1 (pinned host memory, PCIe Gen5 x16) under the kernels of frame i
+    try:
+        nfr = 16
+        hframes = [torch.from_numpy(make_image(40 + i, size)).pin_memory().numpy() for i in range(nfr)]
+        best = None
+        for lanes in (2, 3, 4):
+            bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct, lanes=lanes)
+            bp.keypoints_batch(hframes)
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                res = bp.keypoints_batch(hframes)
+                times.append(time.perf_counter() - t1)
+            tb = sorted(times)[1]
+            if best is None or tb < best[0]:
+                best = (tb, lanes, int(sum(len(r) for r in res)))
+            del bp
+        tb, lanes, nk = best
+        out["pipelined_host"] = {"ms_per_frame": round(1e3 * tb / nfr, 4), "value": round(nfr * size * size / 1e6 / tb, 2), "unit": "Mpix/s",
+                                 "frames_per_call": nfr, "lanes": lanes, "keypoints": nk,
+                                 "h2d_GBps": round(nfr * size * size * 4 / 1e9 / tb, 2),
+                                 "note": "BatchPlan.keypoints_batch over %d pinned HOST frames (numpy in, numpy recarrays out): the 64 MiB "
+                                         "upload of frame i+1 runs under the kernels of frame i; best of lanes = 2, 3, 4" % nfr}
+        del hframes
+    except Exception as exc:
+        out["pipelined_host"] = {"error": str(exc)[:200]}
+    # (2d) BASELINE.json configs[2]: SiftPlan 16384 x 16384 fp32, every octave -- the configuration whose planes (1 GiB each)
+    #      do not fit the 256 MiB Infinity Cache, i.e. where the HBM roofline is about HBM
+    try:
+        out["c3_16384"] = leg_c3(sp, torch, local_rank)
+    except Exception as exc:
+        out["c3_16384"] = {"error": str(exc)[:200]}
+    # (2e) BASELINE.json configs[3] on this one GPU: 64 frames of 2048 x 2048 through a BatchPlan
+    try:
+        out["c4_one_gpu"] = leg_c4(sp, torch, local_rank)
+    except Exception as exc:
+        out["c4_one_gpu"] = {"error": str(exc)[:200]}
     # (3) MatchPlan, BASELINE.json configs[4]: 100k x 100k 128-D uint8 descriptors, L1 + ratio test as the reference
     try:
         n = 100000
@@ -412,7 +564,7 @@ def main():
             # HBM traffic per full-resolution blur launch: not observable from inside this process -- replayed from the
             # committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, tools/summarize_prof.py)
             traffic, traffic_src = None, None
-            for rel in ("profiles/r03/blur_traffic.json",):
+            for rel in ("profiles/r04/blur_traffic.json", "profiles/r03/blur_traffic.json"):
                 tfile = os.path.join(ROOT, rel)
                 if os.path.exists(tfile) and size == SIZE and result["n_oct"] == OCTAVES:
                     try:
@@ -446,6 +598,10 @@ def main():
                                         "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
                                         "ms_per_image": round(pipe_ms / max(K, 1), 4), "time": "hipEvent first -> last kernel" if kt["tot_ms"] > 0 else "wall clock of the timed steps",
                                         "bytes_alg_per_image": bytes_alg(size, size, result["n_oct"], result["kp_per_img"])}
+        if kt is not None and size == SIZE and result["n_oct"] == OCTAVES and world == 1:
+            rv = roofline_valu(1e3 * elapsed / max(K, 1))
+            if rv is not None:
+                out["roofline_valu"] = rv
         if kt is not None and kt.get("steady"):
             out["steady"] = kt["steady"]
         out.update(extra)

@@ -85,9 +85,15 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
 int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsize, int64_t *bytes_allocated);
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
- * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Names: "fused_convert", "overlap", "march",
- * "team", "march_nt", "march_wgs", "march_nb", "ori_blocks", "ori_pad", "desc_blocks", "desc_pad", "desc_stream", "mm_blocks", "chain0", "tile", "ext_rows", "tail", "tail_pixels", "early_pyr", "split_detect", "desc_team", "desc_dynamic", "desc_dense_blocks", "ori_team", "fused_shrink", "fused_refine", "spin",
- * "host_timing".  Unknown name -> SIFTMI_EINVAL. */
+ * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
+ *   launch shapes      "march", "team", "march_nt", "march_wgs", "march_nb", "tile", "mm_blocks", "ext_rows", "ext_strips",
+ *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks",
+ *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_sort", "desc_sort_density",
+ *                      "desc_stream", "maps_blocks"
+ *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",
+ *                      "maps" (0 never / 1 always / 2 by the previous image's count), "maps_density"
+ *   stream schedule    "overlap", "chain0", "early_pyr", "split_detect", "spin"
+ *   diagnostics        "host_timing", "tail_fault" (treat the next n tail launches as timed out: exercises the re-run path) */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 /* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from
  * siftmi_host_alloc: the descriptor kernels write every record straight into it while they run (zero-copy over PCIe),
@@ -126,7 +132,9 @@ int siftmi_plan_transform(siftmi_plan *plan, const void *image, int32_t image_is
 int siftmi_plan_get_minmax(const siftmi_plan *plan, float *min_out, float *max_out);
 int siftmi_plan_profile(const siftmi_plan *plan, char *buf, int64_t buflen);
 /* device time (ms, hipEvent on the plan's stream) of the kernels of the last keypoints() call,
- * excluding host<->device copies; requires profile=1 at creation */
+ * excluding host<->device copies; requires a profile level at creation.  Under the LIGHT level (profile = 1: one event
+ * pair around the octave-0 blur launches and nothing else -- every further event record is a bubble between kernels)
+ * the first and last kernels are not bracketed and *total_ms is 0: only the blur figures are measured. */
 int siftmi_plan_last_kernel_ms(const siftmi_plan *plan, float *total_ms, float *blur_ms, int32_t *blur_launches,
                                double *blur_pixels);
 /* the same restricted to the blur launches of one octave (octave < 0: all).  Octave-0 launches never run
@@ -135,7 +143,8 @@ int siftmi_plan_blur_ms(const siftmi_plan *plan, int32_t octave, float *blur_ms,
                         double *blur_pixels);
 /* running totals of the two figures above over every keypoints() call since the last reset (light profile): what a
  * benchmark loop reads ONCE after its timed region instead of querying events after every call.
- *   calls, total_ms (first -> last kernel of each call, summed), blur0_ms / blur0_launches / blur0_pixels (octave 0) */
+ *   calls, total_ms (first -> last kernel of each call, summed; 0 under the light level, see above), blur0_ms /
+ *   blur0_launches / blur0_pixels (octave 0) */
 int siftmi_plan_profile_totals(siftmi_plan *plan, int32_t reset, int64_t *calls, double *total_ms, double *blur0_ms,
                                int64_t *blur0_launches, double *blur0_pixels);
 int siftmi_plan_destroy(siftmi_plan *plan);

@@ -321,9 +321,17 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
     # and the kind of plan the caller passed (a rank that owns no frame has no plan at all: plan is None there).
     nccl = gather and world_size > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
     on_device = nccl and (plan is None or isinstance(plan, BatchPlan))
+    if nccl:
+        # ... and agreed explicitly: a rank without frames (plan is None) would pick the device path while ranks that were
+        # handed a frame-by-frame SiftPlan pick the host-staged one -- two different collective sequences, i.e. a hang.
+        # One 4-byte all-reduce (MIN) of "this rank can take the device path" settles it for everybody.
+        import torch
+        flag = torch.tensor([1 if on_device else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        on_device = bool(int(flag.item()))
     if on_device:
         import torch
-        if plan is not None:
+        if isinstance(plan, BatchPlan):
             counts, records = plan.keypoints_batch_device([images[i] for i in mine])
         else:                                # empty shard (fewer frames than ranks): joins the collectives with nothing
             counts = []

@@ -206,8 +206,15 @@ __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample 
     }
     const float mag = g * ew;
     o = o - w.angle;
-    while (o > 2.0f * SM_PI_F) o -= 2.0f * SM_PI_F;
-    while (o < 0.0f) o += 2.0f * SM_PI_F;
+    // keypoints_cpu.cl:85-87: while (o > 2 pi) o -= 2 pi; while (o < 0) o += 2 pi.  o and angle lie in [-pi, pi]: the first
+    // loop never runs and the second at most once -- one select; the loops themselves only where a lane is still out of
+    // range after it (wave uniform test; same result: a lane that was negative has had its first addition, the
+    // subtracting loop does not apply to it, and the adding loop continues where the reference's would)
+    if (o < 0.0f) o += 2.0f * SM_PI_F;
+    if (__builtin_expect(__ballot(o > 2.0f * SM_PI_F || o < 0.0f) != 0ull, 0)) {
+        while (o > 2.0f * SM_PI_F) o -= 2.0f * SM_PI_F;
+        while (o < 0.0f) o += 2.0f * SM_PI_F;
+    }
     const float oval = 4.0f * o * SM_1_PI_F;
     const int ri = (int)((rx >= 0.0f) ? rx : rx - 1.0f);
     const int ci = (int)((cx >= 0.0f) ? cx : cx - 1.0f);
@@ -308,6 +315,18 @@ __device__ __forceinline__ float desc_sum_segment(const float4 *pool4, int q, in
     return acc;
 }
 
+// acc + v as one v_add_f32, written out: the compiler otherwise pairs the two chains into v_pk_add_f32 and assembles
+// every operand pair with two v_mov_b32 (8 packed adds + 12 moves per batch; a packed op holds the SIMD for 4.2 cycles,
+// a plain f32 add for 2.4 and lets an integer / LDS-address instruction issue beside it: profiles/r04/valu_issue_rate.txt)
+__device__ __forceinline__ float desc_add(float acc, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(v));
+    return acc;
+#else
+    return acc + v;
+#endif
+}
+
 // The ordered sums of a lane's two bins (adjacent segments: a at group qa, then b).  A bin receives 2.6 values per batch
 // on average and rarely more than eight: the first two groups of both chains are read together (one LDS round trip for
 // both sums of nearly every lane; a lane past its segment reads the four zeros at group 224: +0 is an exact no-op on
@@ -317,14 +336,14 @@ __device__ __forceinline__ void desc_sum_pair(const float4 *pool4, int qa, int e
     const float4 a0 = pool4[ea > 0 ? qa : 224], a1 = pool4[ea > 1 ? qa + 1 : 224];
     const float4 b0 = pool4[eb > 0 ? qb : 224], b1 = pool4[eb > 1 ? qb + 1 : 224];
     __builtin_amdgcn_sched_barrier(0);
-    acc0 = acc0 + a0.x; acc1 = acc1 + b0.x;
-    acc0 = acc0 + a0.y; acc1 = acc1 + b0.y;
-    acc0 = acc0 + a0.z; acc1 = acc1 + b0.z;
-    acc0 = acc0 + a0.w; acc1 = acc1 + b0.w;
-    acc0 = acc0 + a1.x; acc1 = acc1 + b1.x;
-    acc0 = acc0 + a1.y; acc1 = acc1 + b1.y;
-    acc0 = acc0 + a1.z; acc1 = acc1 + b1.z;
-    acc0 = acc0 + a1.w; acc1 = acc1 + b1.w;
+    acc0 = desc_add(acc0, a0.x); acc1 = desc_add(acc1, b0.x);
+    acc0 = desc_add(acc0, a0.y); acc1 = desc_add(acc1, b0.y);
+    acc0 = desc_add(acc0, a0.z); acc1 = desc_add(acc1, b0.z);
+    acc0 = desc_add(acc0, a0.w); acc1 = desc_add(acc1, b0.w);
+    acc0 = desc_add(acc0, a1.x); acc1 = desc_add(acc1, b1.x);
+    acc0 = desc_add(acc0, a1.y); acc1 = desc_add(acc1, b1.y);
+    acc0 = desc_add(acc0, a1.z); acc1 = desc_add(acc1, b1.z);
+    acc0 = desc_add(acc0, a1.w); acc1 = desc_add(acc1, b1.w);
     if (__ballot(ea > 2 || eb > 2)) {                 // wave uniform
         const int nmax = max(ea, eb);
         float4 va = pool4[ea > 2 ? qa + 2 : 224], vb = pool4[eb > 2 ? qb + 2 : 224];
@@ -333,10 +352,10 @@ __device__ __forceinline__ void desc_sum_pair(const float4 *pool4, int qa, int e
             va = pool4[(g4 + 1 < ea) ? qa + g4 + 1 : 224];
             vb = pool4[(g4 + 1 < eb) ? qb + g4 + 1 : 224];
             __builtin_amdgcn_sched_barrier(0);
-            acc0 = acc0 + ca.x; acc1 = acc1 + cb.x;
-            acc0 = acc0 + ca.y; acc1 = acc1 + cb.y;
-            acc0 = acc0 + ca.z; acc1 = acc1 + cb.z;
-            acc0 = acc0 + ca.w; acc1 = acc1 + cb.w;
+            acc0 = desc_add(acc0, ca.x); acc1 = desc_add(acc1, cb.x);
+            acc0 = desc_add(acc0, ca.y); acc1 = desc_add(acc1, cb.y);
+            acc0 = desc_add(acc0, ca.z); acc1 = desc_add(acc1, cb.z);
+            acc0 = desc_add(acc0, ca.w); acc1 = desc_add(acc1, cb.w);
         }
     }
 }

@@ -183,8 +183,23 @@ __device__ __forceinline__ void load_atan_fold(double *lds_tab) {
 
 // binary64 value (normal binary32 range) farther than 2^13 units of 2^-52 from the round-to-nearest boundary of binary32?
 __device__ __forceinline__ bool f32_rounding_is_safe(double v) {
-    const int low = (int)((unsigned)__double2loint(v) & 0x1fffffffu) - 0x10000000;   // 29 discarded bits vs the half-way pattern
-    return (low < 0 ? -low : low) > 8192;
+    // the 29 discarded bits against the half-way pattern 2^28: |low - 2^28| > 8192 as one unsigned range test
+    // (and / add / compare: three instructions; round 3 took the absolute value through min / max / sub: five)
+    const unsigned low = (unsigned)__double2loint(v) & 0x1fffffffu;
+    return (low - (0x10000000u - 8192u)) > 16384u;
+}
+
+// p * r + c as ONE v_fma_f64 with all three operands in registers.  Written out because the compiler selects the
+// two-address v_fmac_f64 for a Horner step and, the coefficient being live across the loop, copies it into the
+// destination first (v_mov_b64 + v_fmac_f64: 13 extra moves per batch of window samples, round-4 disassembly).
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
 }
 
 // exp(x): one-step reduction x = k ln2 + r with a fused two-part ln2 (|r| <= 0.3466, reduction error < 2^-60),
@@ -197,14 +212,14 @@ __device__ __forceinline__ float expf_fast_try(float xf, bool &ok) {
     double r = __builtin_fma(-kd, 0x1.62e42fee00000p-1, x);
     r = __builtin_fma(-kd, 0x1.a39ef35793c76p-33, r);
     double p = 0x1.ae64567f544e4p-26;
-    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+    p = fma3(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma3(p, r, 0x1.71de3a556c734p-19);
+    p = fma3(p, r, 0x1.a01a01a01a01ap-16);
+    p = fma3(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma3(p, r, 0x1.6c16c16c16c17p-10);
+    p = fma3(p, r, 0x1.1111111111111p-7);
+    p = fma3(p, r, 0x1.5555555555555p-5);
+    p = fma3(p, r, 0x1.5555555555555p-3);
     p = __builtin_fma(p, r, 0x1.0p-1);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -242,10 +257,10 @@ __device__ __forceinline__ float atan2f_fast_try(float yf, float xf, const doubl
     const double t = tn * r;
     const double t2 = t * t;
     double p = -0x1.745d1745d1746p-4;
-    p = __builtin_fma(p, t2, 0x1.c71c71c71c71cp-4);
-    p = __builtin_fma(p, t2, -0x1.2492492492492p-3);
-    p = __builtin_fma(p, t2, 0x1.999999999999ap-3);
-    p = __builtin_fma(p, t2, -0x1.5555555555555p-2);
+    p = fma3(p, t2, 0x1.c71c71c71c71cp-4);
+    p = fma3(p, t2, -0x1.2492492492492p-3);
+    p = fma3(p, t2, 0x1.999999999999ap-3);
+    p = fma3(p, t2, -0x1.5555555555555p-2);
     const double at = __builtin_fma(t * t2, p, t);               // atan(t), same sign as t
     const int f = (swap ? 1 : 0) + (__builtin_signbitf(xf) ? 2 : 0);
     const double base = fold[f * 9 + k];

@@ -140,6 +140,8 @@ struct Options {
     int ori_small_blocks = 608;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints (512 until the descriptor launch was ordered: 0.809 ms; 576-640: 0.799-0.801; 704: 0.813)
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
+    int tail_fault = 0;      // diagnostic: the next `tail_fault` images that go through octave_tail_kernel are treated as if a
+                             // workgroup of it had timed out (exercises the host's re-run path; results do not change)
 };
 const Options g_default_options{};
 
@@ -192,6 +194,7 @@ struct siftmi_plan {
     bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves
     int later_group = 1;                      // group index of the later octaves in that image
     hipEvent_t ev_maps0 = nullptr;
+    bool maps_unavailable = false;   // the lazy allocation of the gradient maps failed once: dense frames keep the lazy forms
     hipEvent_t ev_join = nullptr;
     struct HostBack { Counters c, c2; } *hb = nullptr;   // pinned read-back blocks (one asynchronous D->H per ending stream)
     hipStream_t wait_a = nullptr, wait_b = nullptr;      // the stream(s) the image enqueued last ends on
@@ -865,9 +868,11 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
     else if (n == "chain0") o.chain0 = v != 0;
-    else if (n == "early_chain") o.early_chain = v != 0;
     else if (n == "ori_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_small_blocks must be >= 1"); o.ori_small_blocks = v; }
+#ifdef SIFT_DEV_VARIANTS
     else if (n == "bands") { if (v < 0 || v >= SIFT_GROUPS) return fail(SIFTMI_EINVAL, "bands must be in 0..%d", SIFT_GROUPS - 1); o.bands = v; }
+    else if (n == "early_chain") o.early_chain = v != 0;
+#endif
     else if (n == "tile") o.tile = (int)v;
     else if (n == "ext_rows") o.ext_rows = (int)v;
     else if (n == "ext_strips") { if (v < 1) return fail(SIFTMI_EINVAL, "ext_strips must be >= 1"); o.ext_strips = (int)v; }
@@ -889,6 +894,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
+    else if (n == "tail_fault") o.tail_fault = v > 0 ? v : 0;
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
     return SIFTMI_OK;
 }
@@ -1010,7 +1016,9 @@ int enqueue_body(siftmi_plan *p) {
     // strictly serial -- 96 + 20 + 70 us on the headline frame before the first descriptor wave starts -- and the
     // memory-bound detection never overlaps the issue-bound description.  Groups 0 .. nbands - 1 are the bands, group
     // `later` the later octaves.
+    // DEVELOPMENT BUILDS ONLY (SIFT_DEV_VARIANTS): measured slower on every frame (Options::bands); the product path is unbanded.
     int nbands = 0;
+#ifdef SIFT_DEV_VARIANTS
     if (chain0 && p->opt.bands > 1 && p->n_oct > 0 && p->profile <= 1 && march_plane(p->ow[0], p->oh[0]) && tail_first != 0 &&
         p->ow[0] > 2 * p->par.border_dist && p->oh[0] > 2 * p->par.border_dist) {
         nbands = std::min(p->opt.bands, SIFT_GROUPS - 1);
@@ -1022,6 +1030,7 @@ int enqueue_body(siftmi_plan *p) {
             p->ev_kp.push_back(a); p->ev_out.push_back(b);
         }
     }
+#endif
     p->bands_last = nbands;
     const int later = nbands ? nbands : 1;         // group index of the later octaves
     // Gradient maps for the per-keypoint kernels of this image (option "maps"): large frames, by the previous image's counts
@@ -1042,8 +1051,19 @@ int enqueue_body(siftmi_plan *p) {
             // first keypoint-rich image of this plan: two maps of half the pyramid's size each (three planes per octave)
             float *g = nullptr, *o = nullptr;
             const size_t bytes = (p->planes_floats / 2 + 16) * sizeof(float);
-            if (p->alloc(&g, bytes) == SIFTMI_OK && p->alloc(&o, bytes) == SIFTMI_OK) { p->gmap = g; p->omap = o; p->bytes += 2 * (int64_t)bytes; }
-            else { want0 = want1 = false; (void)hipGetLastError(); }      // no room: the lazy forms
+            if (!p->maps_unavailable && p->alloc(&g, bytes) == SIFTMI_OK) {          // (alloc() keeps the books: allocs, bytes)
+                if (p->alloc(&o, bytes) == SIFTMI_OK) { p->gmap = g; p->omap = o; }
+                else {                       // half a pair is of no use: give it back instead of holding it until the plan dies
+                    (void)hipFree(g);
+                    p->allocs.pop_back();
+                    p->bytes -= (int64_t)bytes;
+                }
+            }
+            if (!p->gmap) {                  // no room: the lazy forms, and no further attempt (a hipMalloc synchronises the device)
+                p->maps_unavailable = true;
+                want0 = want1 = false;
+                (void)hipGetLastError();
+            }
         }
         p->maps_g0 = want0; p->maps_g1 = want1; p->later_group = later;
         if (want0 && two && !p->ev_maps0) HIPCHK(hipEventCreateWithFlags(&p->ev_maps0, hipEventDisableTiming));
@@ -1148,7 +1168,7 @@ int enqueue_body(siftmi_plan *p) {
             if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
             if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, (oct == 0 && pyr0_done) ? pyr0_done : p->ev_pyr[(size_t)oct], 0));
         }
-        if (oct == 0 && p->maps_g0 && two && !nbands) HIPCHK(hipStreamWaitEvent(dst, p->ev_maps0, 0));     // (banded: the orientation launches follow the maps on stream2)
+#ifdef SIFT_DEV_VARIANTS
         if (oct == 0 && nbands) {
             for (int b = 0; b < nbands; b++) {
                 launch_detect_octave(p, 0, p->stream, b, nbands);
@@ -1162,7 +1182,10 @@ int enqueue_body(siftmi_plan *p) {
             HIPCHK(hipEventRecord(p->ev_mark0, p->stream2));     // every range of octave 0 is frozen: the later octaves may append
             continue;
         }
+#endif
         launch_detect_octave(p, oct, dst);
+        // octave 0's gradient maps ran on the idle stream beside detection and refinement: only orientation and description read them
+        if (oct == 0 && p->maps_g0 && two) HIPCHK(hipStreamWaitEvent(dst, p->ev_maps0, 0));
         if (oct == 0) launch_describe_group(p, 0, dst, p->overlap ? p->ev_mark0 : nullptr);
         else if (oct == p->n_oct - 1) {
             hipStream_t ds = two ? p->stream3 : p->stream;        // group 1 is described (and the image ends) on stream3
@@ -1229,7 +1252,9 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
         p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
     }
-    if (p->hb->c.tail_timeout || (p->wait_b && p->hb->c2.tail_timeout)) {
+    bool tail_timed_out = p->hb->c.tail_timeout || (p->wait_b && p->hb->c2.tail_timeout);
+    if (!tail_timed_out && p->opt.tail_fault > 0 && p->opt.tail) { p->opt.tail_fault--; tail_timed_out = true; }   // injected (option "tail_fault")
+    if (tail_timed_out) {
         // a workgroup of octave_tail_kernel stopped waiting for the octave above (k_tail.hpp): this image is incomplete.
         // From now on the plan walks the small octaves with the per-octave launches; the caller runs the image again.
         p->opt.tail = 0;
@@ -1384,6 +1409,9 @@ struct siftmi_batch {
     int64_t blur0_launches = 0;
     siftmi_keypoint *const *host_outs = nullptr;   // optional: one caller-owned host array per frame, filled while the batch runs
     const int64_t *host_caps = nullptr;            // their capacities in records (a frame that does not fit stays parked in the arena)
+    const void *const *cur_images = nullptr;       // the frames of the call in progress (a lane re-runs its frame after a tail time-out)
+    int32_t cur_dtype = 0, cur_is_device = 0;
+    int64_t tail_retries = 0;                      // frames re-run since the batch was created
 };
 extern "C" {
 
@@ -1471,7 +1499,15 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     if (img >= b->batch_size) { b->lane_image[l] = -1; return fail(SIFTMI_EINVAL, "stale frame index %d on lane %zu", img, l); }
     int64_t n = 0; int32_t ovf = 0;
     int rc = plan_wait(p, &n, &ovf);
-    if (rc == SIFTMI_ETAILRETRY) rc = SIFTMI_EDEVICE;     // the frame is gone from the batch's lanes: report, do not retry here
+    if (rc == SIFTMI_ETAILRETRY && b->cur_images) {
+        // a workgroup of octave_tail_kernel gave up waiting (k_tail.hpp: most likely queued behind another lane's persistent
+        // descriptor workgroups -- a batch-only condition).  plan_wait has drained the lane and switched it to the per-octave
+        // launches: the frame runs once more on the same lane, as siftmi_plan_keypoints does for a single plan.
+        b->tail_retries++;
+        rc = plan_enqueue(p, b->cur_images[img], b->cur_dtype, b->cur_is_device, false);
+        if (!rc) rc = plan_wait(p, &n, &ovf);
+    }
+    if (rc == SIFTMI_ETAILRETRY) rc = fail(SIFTMI_EDEVICE, "octave_tail_kernel timed out twice on frame %d", img);
     if (rc) return rc;
     if (ovf && overflow) *overflow = 1;
     if (p->profile) {
@@ -1550,6 +1586,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     b->retired = 0; b->batch_size = n_images;
     b->blur0_ms = 0; b->blur0_pixels = 0; b->blur0_launches = 0;
     b->host_outs = host_outs; b->host_caps = host_caps;
+    b->cur_images = images; b->cur_dtype = image_dtype; b->cur_is_device = images_are_device;
     b->counts.assign((size_t)n_images, 0);
     b->offsets.assign((size_t)n_images, 0);
     if (images_are_device) HIPCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams
@@ -1572,7 +1609,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     }
     if (htime) fprintf(stderr, "[siftmi] batch of %d: waiting for lanes %.0f us, enqueueing %.0f us\n", n_images, t_retire, t_enqueue);
     for (int i = n_images > (int)L ? n_images - (int)L : 0; i < n_images && !rc; i++) rc = batch_retire(b, (size_t)i % L, overflow);
-    b->host_outs = nullptr; b->host_caps = nullptr;
+    b->host_outs = nullptr; b->host_caps = nullptr; b->cur_images = nullptr;
     if (rc) { std::string keep = g_err; batch_drain(b); g_err = keep; return rc; }
     HIPCHK(hipDeviceSynchronize());                            // the parking copies
     for (int i = 0; i < n_images; i++) { counts[i] = b->counts[(size_t)i]; offsets[i] = b->offsets[(size_t)i]; }

@@ -115,7 +115,8 @@ class SiftPlan(object):
             raise RuntimeError("par.Scales is hard-wired to 3 in the kernels (as in image.cl:355)")
         self.profile = bool(profile)
         # profile=True: hipEvent bracket around every stage (log_profile(), as the reference);
-        # profile="light": only the blur launches and the first/last kernel (what bench.py needs)
+        # profile="light": ONE event pair around the octave-0 blur launches and nothing else (what bench.py needs);
+        # the first / last kernels are not bracketed at that level: kernel_times()["total_ms"] is 0
         self._profile_level = 0 if not profile else (1 if profile == "light" else 2)
         self.events = []
         self._sem = threading.Semaphore()
@@ -348,7 +349,8 @@ class SiftPlan(object):
         return out
 
     def kernel_times(self):
-        """dict(total_ms, blur_ms, blur_launches, blur_pixels) of the last call (profile=True)."""
+        """dict(total_ms, blur_ms, blur_launches, blur_pixels) of the last call (profile=True; with profile="light" only
+        the blur figures are measured and total_ms is 0)."""
         tot, blur = C.c_float(), C.c_float()
         nl, px = C.c_int32(), C.c_double()
         _lib.check(_lib.lib().siftmi_plan_last_kernel_ms(self._handle, C.byref(tot), C.byref(blur), C.byref(nl), C.byref(px)))
@@ -359,7 +361,7 @@ class SiftPlan(object):
 
     def profile_totals(self, reset=False):
         """Running totals of ``kernel_times()`` over every call since the last reset (profile="light"): dict(calls,
-        total_ms, blur0_ms, blur0_launches, blur0_pixels).  A benchmark loop reads this once after its timed region."""
+        total_ms, blur0_ms, blur0_launches, blur0_pixels); total_ms stays 0 under the light profile (no first / last events).  A benchmark loop reads this once after its timed region."""
         calls, nl = C.c_int64(), C.c_int64()
         tot, b0, px = C.c_double(), C.c_double(), C.c_double()
         _lib.check(_lib.lib().siftmi_plan_profile_totals(self._handle, int(bool(reset)), C.byref(calls), C.byref(tot), C.byref(b0),

@@ -99,3 +99,22 @@ def test_c4_shape_16_lanes_against_the_oracle(siftlib, oracle):
     back = split_gathered([counts], records.view(1, -1), 16, 1)
     for i in range(16):
         assert_same_keypoints(back[i], got[i], "device hand-back, frame %d" % i)
+
+
+def test_tail_timeout_reruns_the_frame(siftlib, oracle):
+    """a time-out of octave_tail_kernel must re-run the frame -- for a single plan (siftmi_plan_keypoints) and
+    for a lane of a batch (batch_retire), where it used to fail the whole call.  Option "tail_fault" = n treats the next n
+    tail launches as timed out; the results must not change, and afterwards the plan walks the small octaves launch by launch."""
+    import sift_pyocl_amd as sp
+    frames = [white_noise((256, 320), seed=40 + i) for i in range(6)]
+    want = [oracle.keypoints(f) for f in frames]
+    plan = sp.SiftPlan(template=frames[0])
+    plan.set_option("tail_fault", 1)
+    for f, w in zip(frames[:3], want[:3]):              # the first call is the one that is run twice
+        assert_same_keypoints(plan.keypoints(f), w, "single plan, injected tail time-out")
+    bp = sp.BatchPlan(template=frames[0], lanes=3)
+    bp.set_option("tail_fault", 1)                      # every lane re-runs its first frame
+    for got, w in zip(bp.keypoints_batch(frames), want):
+        assert_same_keypoints(got, w, "batch lane, injected tail time-out")
+    for got, w in zip(bp.keypoints_batch(frames), want):
+        assert_same_keypoints(got, w, "batch, call after the re-run")

@@ -76,9 +76,11 @@ def test_2048_keypoint_rich_bit_exact(siftlib, oracle):
     assert len(got) > 30000
     want = oracle.keypoints(img)
     assert_same_keypoints(got, want, "2048 smoothed noise")
-    # launch-layout options that only large frames reach (none may change a byte): the band pipeline of octave 0, the early
-    # start of the later octaves' chain, detection on its own stream -- each with the lazy gradient and with full maps
-    for opts in (dict(bands=4), dict(bands=2, early_chain=1), dict(early_chain=1), dict(split_detect=1), dict(early_pyr=1), dict(chain0=0)):
+    # launch-layout options that only large frames reach (none may change a byte): detection on its own stream, the early
+    # enqueue of octave 1's pyramid, the round-1 stream layout -- each with the lazy gradient and with full maps.  (The band
+    # pipeline of octave 0 and the early start of the later octaves' chain, both measured slower, exist in development
+    # builds only since round 4: SIFT_DEV_VARIANTS.)
+    for opts in (dict(split_detect=1), dict(early_pyr=1), dict(chain0=0)):
         for maps in (0, 1):
             p2 = sp.SiftPlan(template=img)
             p2.set_option("maps", maps)

@@ -1,0 +1,69 @@
+"""Self-arming N > 1 test: on a box with at least two GPUs the RCCL path ("nccl" backend, one GPU per rank) is validated
+without anyone writing code that day; on a one-GPU box it skips and says why.
+
+What it checks when it runs:
+  * tests/multi_worker.py under torch.distributed.run with 2 ranks: batch.keypoints_batch over nccl equals a single-rank
+    BatchPlan per frame, byte for byte (uneven shard, empty shard), batch.match_sharded with a MatchPlan per rank equals
+    MatchPlan.match of the whole lists;
+  * bench.py --gpus 2 (its own launcher) and bench.py --config c4 --gpus 2: the process group observed 2 ranks on the
+    nccl backend, the exchange ran on device tensors, and the C4 keypoint count per frame equals the one-GPU run's.
+The one-GPU rehearsals of the same code paths (gloo, both ranks on cuda:0) are tests/test_gpu_bench_contract.py and, on
+CPU, tests/test_batch_gloo.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def n_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+needs_two = pytest.mark.skipif(n_gpus() < 2, reason="RCCL needs one GPU per rank: %d GPU(s) visible; rehearsed over gloo in "
+                                                    "tests/test_gpu_bench_contract.py and tests/test_batch_gloo.py" % n_gpus())
+
+
+def env():
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return e
+
+
+def bench(args, timeout=900):
+    out = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=timeout, text=True, env=env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@needs_two
+def test_sharded_paths_over_rccl_equal_one_rank():
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29547", os.path.join("tests", "multi_worker.py")], cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True, env=env())
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert "multi ok: 2 ranks over nccl" in out.stdout
+
+
+@needs_two
+def test_bench_two_gpus_over_rccl():
+    d = bench(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["config"]["backend"] == "nccl"
+    assert "all_gather" in d["config"]["exchange"] and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 4096 * 4096 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+
+
+@needs_two
+def test_bench_c4_two_gpus_over_rccl():
+    d = bench(["--config", "c4", "--gpus", "2", "--steps", "1", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["config"]["backend"] == "nccl"
+    one = bench(["--config", "c4", "--steps", "1", "--warmup", "1"])
+    assert abs(one["config"]["keypoints_per_image"] - d["config"]["keypoints_per_image"]) < 1e-6

@@ -1409,6 +1409,14 @@ struct siftmi_batch {
     int64_t blur0_launches = 0;
     siftmi_keypoint *const *host_outs = nullptr;   // optional: one caller-owned host array per frame, filled while the batch runs
     const int64_t *host_caps = nullptr;            // their capacities in records (a frame that does not fit stays parked in the arena)
+    // host frames: uploads run on ONE copy stream, in frame order, one frame ahead of the kernel enqueue, into a ring of
+    // lanes + 1 staging buffers (a lane's own staging buffer would hold its next upload back until its frame has retired:
+    // with two lanes both uploads then share the link, both pyramids start together and the link idles while they run --
+    // 4096^2 frames: 1.53 ms per frame against 1.16 ms of PCIe time)
+    std::vector<void *> ring;
+    std::vector<hipEvent_t> ring_ev;
+    size_t ring_bytes = 0;
+    hipStream_t copy_stream = nullptr;
     const void *const *cur_images = nullptr;       // the frames of the call in progress (a lane re-runs its frame after a tail time-out)
     int32_t cur_dtype = 0, cur_is_device = 0;
     int64_t tail_retries = 0;                      // frames re-run since the batch was created
@@ -1420,6 +1428,9 @@ int siftmi_batch_destroy(siftmi_batch *b) {
     for (siftmi_plan *p : b->lanes) siftmi_plan_destroy(p);
     hipSetDevice(b->device);
     if (b->arena) hipFree(b->arena);
+    for (void *q : b->ring) hipFree(q);
+    for (hipEvent_t e : b->ring_ev) hipEventDestroy(e);
+    if (b->copy_stream) hipStreamDestroy(b->copy_stream);
     delete b;
     return SIFTMI_OK;
 }
@@ -1504,7 +1515,9 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
         // descriptor workgroups -- a batch-only condition).  plan_wait has drained the lane and switched it to the per-octave
         // launches: the frame runs once more on the same lane, as siftmi_plan_keypoints does for a single plan.
         b->tail_retries++;
-        rc = plan_enqueue(p, b->cur_images[img], b->cur_dtype, b->cur_is_device, false);
+        // (a host frame is still in its ring slot: the slot is not reused before its frame has retired)
+        const bool staged = !b->cur_is_device && !b->ring.empty();
+        rc = plan_enqueue(p, staged ? b->ring[(size_t)img % b->ring.size()] : b->cur_images[img], b->cur_dtype, staged ? 1 : b->cur_is_device, false);
         if (!rc) rc = plan_wait(p, &n, &ovf);
     }
     if (rc == SIFTMI_ETAILRETRY) rc = fail(SIFTMI_EDEVICE, "octave_tail_kernel timed out twice on frame %d", img);
@@ -1595,6 +1608,33 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     const bool htime = L > 0 && b->lanes[0]->opt.host_timing;   // diagnostic: where the host thread spends the batch
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_retire = 0, t_enqueue = 0;
+    // host frames go through the upload ring (see siftmi_batch)
+    const bool staged = !images_are_device && n_images > 0 && L > 0;
+    const size_t frame_bytes = staged ? (size_t)b->lanes[0]->H * b->lanes[0]->W * dtype_size(image_dtype) : 0;
+    if (staged) {
+        if (b->ring_bytes < frame_bytes || b->ring.size() != L + 1) {
+            HIPCHK(hipDeviceSynchronize());
+            for (void *q : b->ring) hipFree(q);
+            b->ring.clear(); b->ring_bytes = 0;
+            for (size_t k = 0; k < L + 1; k++) {
+                void *q = nullptr;
+                hipError_t e = hipMalloc(&q, frame_bytes);
+                if (e != hipSuccess) { b->host_outs = nullptr; b->host_caps = nullptr; b->cur_images = nullptr; return fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", frame_bytes, hipGetErrorString(e)); }
+                b->ring.push_back(q);
+            }
+            b->ring_bytes = frame_bytes;
+        }
+        while (b->ring_ev.size() < L + 1) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); b->ring_ev.push_back(e); }
+        if (!b->copy_stream) HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    }
+    auto upload = [&](int i) -> int {             // frame i -> ring slot i % (L + 1); the slot's previous frame (i - L - 1) has retired
+        if (!images[i]) return fail(SIFTMI_EINVAL, "null image %d", i);
+        const size_t k = (size_t)i % (L + 1);
+        HIPCHK(hipMemcpyAsync(b->ring[k], images[i], frame_bytes, hipMemcpyHostToDevice, b->copy_stream));
+        HIPCHK(hipEventRecord(b->ring_ev[k], b->copy_stream));
+        return SIFTMI_OK;
+    };
+    if (staged) rc = upload(0);
     for (int i = 0; i < n_images && !rc; i++) {
         if (!images[i]) { rc = fail(SIFTMI_EINVAL, "null image %d", i); break; }
         const size_t l = (size_t)i % L;
@@ -1602,6 +1642,13 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
         if ((rc = batch_retire(b, l, overflow))) break;
         const double tb = htime ? tnow() : 0;
         if (htime) b->lanes[l]->opt.host_timing = 0;             // the per-call line would flood
+        if (staged) {
+            // frame i - L has just retired, so has every earlier one: slot (i + 1) % (L + 1), last used by frame i - L, is free
+            if (i + 1 < n_images && (rc = upload(i + 1))) break;
+            const size_t k = (size_t)i % (L + 1);
+            HIPCHK(hipStreamWaitEvent(b->lanes[l]->stream, b->ring_ev[k], 0));
+            rc = plan_enqueue(b->lanes[l], b->ring[k], image_dtype, 1, false);
+        } else
         rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false);
         if (htime) { b->lanes[l]->opt.host_timing = 1; t_retire += tb - ta; t_enqueue += tnow() - tb; }
         if (rc) break;
@@ -1610,7 +1657,13 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     if (htime) fprintf(stderr, "[siftmi] batch of %d: waiting for lanes %.0f us, enqueueing %.0f us\n", n_images, t_retire, t_enqueue);
     for (int i = n_images > (int)L ? n_images - (int)L : 0; i < n_images && !rc; i++) rc = batch_retire(b, (size_t)i % L, overflow);
     b->host_outs = nullptr; b->host_caps = nullptr; b->cur_images = nullptr;
-    if (rc) { std::string keep = g_err; batch_drain(b); g_err = keep; return rc; }
+    if (rc) {                                // nothing of this call may still read the caller's frames or write its arrays
+        std::string keep = g_err;
+        if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+        batch_drain(b);
+        g_err = keep;
+        return rc;
+    }
     HIPCHK(hipDeviceSynchronize());                            // the parking copies
     for (int i = 0; i < n_images; i++) { counts[i] = b->counts[(size_t)i]; offsets[i] = b->offsets[(size_t)i]; }
     *total_parked = (int64_t)(b->arena_used / sizeof(KpRecord));

@@ -87,7 +87,7 @@ def test_orientation_against_the_numpy_restatement(oracle, data, s):
     key = lambda a: a[np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0]))]   # noqa: E731
     gs, ws = key(got), key(want)
     assert np.abs(gs[:, :3] - ws[:, :3]).max() < 1e-4
-    assert np.abs(gs[:, 3] - ws[:, 3]).max() < 2e-2
+    assert np.abs(gs[:, 3] - ws[:, 3]).max() < 1e-5          # measured: 4.8e-7 (132 oriented keypoints)
 
 
 @pytest.mark.parametrize("s", [1, 2, 3])
@@ -101,8 +101,9 @@ def test_descriptor_against_the_numpy_restatement(oracle, data, s):
     diff = np.abs(got - want)
     # "several difference of 1" (test_keypoints.py:300): float32 accumulation in raster order against float64; the numpy
     # version also clamps with (vec > 0.2) on EVERY descriptor and renormalises all of them if any was clamped
-    assert diff.max() <= 2, "largest bin difference %d" % diff.max()
-    assert (diff > 1).mean() < 1e-3 and (diff > 0).mean() < 0.12
+    # measured on the 132 descriptors of this image: every one of the 16 896 bins is EQUAL
+    assert diff.max() <= 1, "largest bin difference %d" % diff.max()
+    assert (diff > 0).mean() < 0.01
 
 
 def test_matching_against_the_numpy_restatement(oracle, data):

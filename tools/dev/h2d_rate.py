@@ -17,11 +17,21 @@ for mode in ("one stream", "two streams"):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("%-12s: %.3f ms per 64 MiB copy = %.1f GB/s" % (mode, 1e3 * dt / 32, 32 * n * 4 / dt / 1e9))
 frames = [torch.from_numpy(np.random.default_rng(40 + i).random((4096, 4096), dtype=np.float32)).pin_memory().numpy() for i in range(16)]
-for lanes in (2, 3, 4):
+import ctypes
+L = sp._lib.lib()
+L.hipMemcpyLike = None
+raw = torch.empty(n, dtype=torch.float32, device="cuda")
+plan1 = sp.SiftPlan(shape=(4096, 4096), dtype=np.float32, octave_max=3)
+for _ in range(3): plan1.keypoints(frames[0])
+t0 = time.perf_counter()
+for i in range(8): plan1.keypoints(frames[i])
+print("SiftPlan host frame, synchronous: %.3f ms per frame" % (1e3 * (time.perf_counter() - t0) / 8))
+del plan1
+for lanes, split in ((2, 0), (3, 0), (4, 0)):
     bp = sp.BatchPlan(shape=(4096, 4096), dtype=np.float32, octave_max=3, lanes=lanes)
     bp.keypoints_batch(frames)
     ts = []
     for _ in range(4):
         t0 = time.perf_counter(); bp.keypoints_batch(frames); ts.append(time.perf_counter() - t0)
-    print("BatchPlan host frames, %d lanes: %.3f ms per frame (best %.3f)" % (lanes, 1e3 * sorted(ts)[1] / 16, 1e3 * min(ts) / 16))
+    print("BatchPlan host frames, %d lanes, split %d: %.3f ms per frame (best %.3f)" % (lanes, split, 1e3 * sorted(ts)[1] / 16, 1e3 * min(ts) / 16))
     del bp

@@ -114,6 +114,7 @@ class LinearAlign(object):
         """Install `kp` (ROI-filtered) as the reference list and keep a copy resident on the device
         (the reference's buffers["ref_kp_gpu"], alignment.py:155-157)."""
         self.ref_kp = self._mask(kp)
+        self._ref_heads = None               # dense (n, 4) copy of (x, y, scale, angle), built on first use
         self._upload_ref()
 
     def _upload_ref(self):
@@ -148,10 +149,13 @@ class LinearAlign(object):
         offset = numpy.ascontiguousarray(offset, numpy.float32).reshape(2)
         if fill is None:
             fill = self.sift.minmax()[0]
-        if self.RGB:
-            out = numpy.empty(self.outshape + (3,), numpy.uint8)
-        else:
-            out = numpy.empty(self.outshape, numpy.float32)
+        # the result image lives in a pinned block of the library's pool (recycled when the caller drops it): the copy out
+        # of HBM runs at the link's rate, and no 64 MB mmap / munmap pair per aligned frame (see SiftPlan.keypoints)
+        oshape, odtype = (self.outshape + (3,), numpy.uint8) if self.RGB else (self.outshape, numpy.float32)
+        try:
+            out = _lib.pinned_empty(int(numpy.prod(oshape)), odtype).reshape(oshape)
+        except MemoryError:
+            out = numpy.empty(oshape, odtype)
         ptr = None
         if image is not None:
             image = numpy.ascontiguousarray(image, numpy.uint8 if self.RGB else numpy.float32)
@@ -238,8 +242,12 @@ class LinearAlign(object):
             # the 144-byte records; the reference's `matching` recarray (alignment.py:254-259) is only materialised for
             # ORSA and for return_all.
             ref_used = self.ref_kp
-            g0 = self._xysa(ref_used)[pairs[:, 0]]
-            g1 = self._xysa(kp)[pairs[:, 1]]
+            # (the 16-byte heads are first packed into a dense (n, 4) array -- one strided pass -- and indexed there: a fancy
+            # index straight into the 144-byte records took 13 ms for 2 x 195 k pairs, this takes 3)
+            if self._ref_heads is None:
+                self._ref_heads = numpy.ascontiguousarray(self._xysa(ref_used))
+            g0 = self._ref_heads[pairs[:, 0]]
+            g1 = numpy.ascontiguousarray(self._xysa(kp))[pairs[:, 1]]
 
             def matched_records():
                 both = numpy.recarray(shape=pairs.shape, dtype=MatchPlan.dtype_kp)
@@ -274,10 +282,11 @@ class LinearAlign(object):
         if not return_all:
             return result
         # residual of the fitted map on the matched keypoints, in pixels (alignment.py:349-351)
-        src_yx = numpy.stack((g0[:, 1], g0[:, 0]))
-        dst_yx = numpy.stack((g1[:, 1], g1[:, 0]))
-        resid = numpy.dot(matrix, src_yx).T + offset.T - dst_yx.T
-        rms = numpy.sqrt((resid * resid).sum(axis=-1).mean())
+        # (written out instead of numpy.dot(matrix, src): a threaded BLAS has no business in a 2 x 2 product, see utils.py)
+        sy, sx = g0[:, 1], g0[:, 0]
+        ry = matrix[0, 0] * sy + matrix[0, 1] * sx + offset[0] - g1[:, 1]
+        rx = matrix[1, 0] * sy + matrix[1, 1] * sx + offset[1] - g1[:, 0]
+        rms = numpy.sqrt((ry * ry + rx * rx).mean())
         if matching is None:
             matching = matched_records()
         return {"result": result, "keypoint": kp, "matching": matching, "offset": offset, "matrix": matrix, "rms": rms}

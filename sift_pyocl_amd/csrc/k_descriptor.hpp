@@ -123,6 +123,76 @@ __device__ __forceinline__ float f32_neighbour(float x, bool up) {
     return __int_as_float(((b >= 0) == up) ? b + 1 : b - 1);
 }
 
+
+// Row interval of window row ii (keypoints_cpu.cl:64-72): the first in-window jj and the number of in-window samples.
+// The four flips of the row's predicates are monotone false -> true in jj (see 1. above).  Each is located by a CLOSED-FORM
+// BRACKET: the real crossing of the linear expression, x* = (ci_ - drow - T) / sine (resp. (T + dcol - si_) / cosine), lies
+// within a fraction of a step of the float expression's flip, so the exact predicate is evaluated at four consecutive
+// integers around floor(x*) and the flip is read off; positions outside [-R, R] count as false below and true above.
+// A lane whose four evaluations do not contain a false -> true step (an estimate that is off: sine == 0, NaN) reports
+// failure and the caller runs the bisection for the whole wave -- the result is the same either way, the bracket only
+// replaces ~6 bisection rounds of four evaluations each (round 4: ~700 of a keypoint's ~2400 set-up instructions).
+struct DescRowSearch {
+    float sine, cosine, drow, dcol, t_hi, t_lo, rsine, rcosine;
+    int R;
+    bool rdec, cdec;
+};
+template <int Q>
+__device__ __forceinline__ bool desc_row_pred(const DescRowSearch &q, float ci_, float si_, int k) {
+    const float fj = (float)k;
+    const float u = (Q < 2) ? ((ci_ - q.sine * fj) - q.drow) : ((si_ + q.cosine * fj) - q.dcol);
+    const bool dec = (Q < 2) ? q.rdec : q.cdec;
+    // Q even: first jj inside the band; Q odd: first jj beyond it (thresholds verified by the caller: thr_ok)
+    if ((Q & 1) == 0) return dec ? (u < q.t_hi) : (u > q.t_lo);
+    return dec ? !(u > q.t_lo) : !(u < q.t_hi);
+}
+template <int Q>
+__device__ __forceinline__ int desc_row_flip(const DescRowSearch &q, float ci_, float si_, bool &ok) {
+    const bool dec = (Q < 2) ? q.rdec : q.cdec;
+    const float T = ((Q & 1) == 0) ? (dec ? q.t_hi : q.t_lo) : (dec ? q.t_lo : q.t_hi);
+    const float xs = (Q < 2) ? ((ci_ - q.drow) - T) * q.rsine : ((T + q.dcol) - si_) * q.rcosine;
+    // (a NaN / infinite estimate lands anywhere in the clamp range: the step test below decides)
+    const int k0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(xs) - 1.0f, (float)(-q.R - 2)), (float)(q.R - 2));
+    // monotone false -> true: the flip is k0 + 1 + (number of false among positions 1 and 2), provided position 0 is false and
+    // position 3 true (otherwise the flip lies outside the four positions: no claim)
+    auto at = [&](int e) { const int k = k0 + e; return (k > q.R) || (k >= -q.R && desc_row_pred<Q>(q, ci_, si_, k)); };
+    int f = k0 + 1;
+    ok = ok && !at(0);
+    f += at(1) ? 0 : 1;
+    f += at(2) ? 0 : 1;
+    ok = ok && at(3);
+    return f;
+}
+
+
+// The bisection the bracket replaces: exact for any row, used where the thresholds could not be verified (thr_ok false: the
+// predicates then evaluate g(u) = u / spacing + 1.5f itself) or a lane's bracket found no step.  Not inlined: it runs for
+// a handful of keypoints per image and would otherwise hold its registers across the common path.
+__device__ __attribute__((noinline)) int4 desc_row_bisect(const DescRowSearch q, float spacing, bool thr_ok, int iters, float ci_, float si_) {
+    auto g = [&](float u) { return u / spacing + 1.5f; };
+    auto below_hi = [&](float u) { return thr_ok ? (u < q.t_hi) : (g(u) < 4.0f); };
+    auto above_lo = [&](float u) { return thr_ok ? (u > q.t_lo) : (g(u) > -1.0f); };
+    int lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { lo[k] = -q.R; hi[k] = q.R + 1; }
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int mid = (lo[k] + hi[k]) >> 1;
+            const float fj = (float)mid;
+            const float u = (k < 2) ? ((ci_ - q.sine * fj) - q.drow) : ((si_ + q.cosine * fj) - q.dcol);
+            const bool dec = (k < 2) ? q.rdec : q.cdec;
+            // k even: first jj inside the band; k odd: first jj beyond it (monotone false ... true predicates)
+            bool pred;
+            if ((k & 1) == 0) pred = dec ? below_hi(u) : above_lo(u);
+            else pred = dec ? !above_lo(u) : !below_hi(u);
+            if (lo[k] < hi[k]) { if (pred) hi[k] = mid; else lo[k] = mid + 1; }
+        }
+    }
+    return make_int4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 // what is the same for every sample of a keypoint's window (wave uniform)
 struct DescWindow {
     const float *I;            // blur[scale] of the keypoint's octave
@@ -452,27 +522,20 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         const int iters = 32 - __clz(S);         // 2R + 2 candidate positions
         int carry = 0;
         for (int r0 = 0; r0 < S; r0 += 64) {
+            const DescRowSearch rs = {sine, cosine, drow, dcol, t_hi, t_lo, __builtin_amdgcn_rcpf(sine), __builtin_amdgcn_rcpf(cosine), R, rdec, cdec};
             const int r = r0 + lane;
             const int ii = r - R;
             const float fi = (float)ii;
             const float ci_ = cosine * fi, si_ = sine * fi;
-            int lo[4], hi[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { lo[q] = -R; hi[q] = R + 1; }
-#pragma unroll 1
-            for (int it = 0; it < iters; it++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int mid = (lo[q] + hi[q]) >> 1;
-                    const float fj = (float)mid;
-                    const float u = (q < 2) ? ((ci_ - sine * fj) - drow) : ((si_ + cosine * fj) - dcol);
-                    const bool dec = (q < 2) ? rdec : cdec;
-                    // q even: first jj inside the band; q odd: first jj beyond it (monotone false ... true predicates)
-                    bool pred;
-                    if ((q & 1) == 0) pred = dec ? below_hi(u) : above_lo(u);
-                    else pred = dec ? !above_lo(u) : !below_hi(u);
-                    if (lo[q] < hi[q]) { if (pred) hi[q] = mid; else lo[q] = mid + 1; }
-                }
+            int lo[4];
+            bool bracket_ok = thr_ok;
+            if (thr_ok) {                                // wave uniform
+                lo[0] = desc_row_flip<0>(rs, ci_, si_, bracket_ok); lo[1] = desc_row_flip<1>(rs, ci_, si_, bracket_ok);
+                lo[2] = desc_row_flip<2>(rs, ci_, si_, bracket_ok); lo[3] = desc_row_flip<3>(rs, ci_, si_, bracket_ok);
+            }
+            if (__ballot(!bracket_ok)) {                 // wave uniform, rare: the bisection (exact for every lane)
+                const int4 b4 = desc_row_bisect(rs, spacing, thr_ok, iters, ci_, si_);
+                lo[0] = b4.x; lo[1] = b4.y; lo[2] = b4.z; lo[3] = b4.w;
             }
             const int jlo = max(max(lo[0], lo[2]), max(-R, -icol));
             const int jhi = min(min(lo[1], lo[3]) - 1, min(R, W - 1 - icol));
@@ -627,23 +690,17 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
             const int ii = r - R;
             const float fi = (float)ii;
             const float ci_ = cosine * fi, si_ = sine * fi;
-            int lo[4], hi[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { lo[q] = -R; hi[q] = R + 1; }
+            int lo[4] = {-R, -R, -R, -R};
             if (64 * wave < S) {                                      // wave uniform
-#pragma unroll 1
-                for (int it = 0; it < iters; it++) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int mid = (lo[q] + hi[q]) >> 1;
-                        const float fj = (float)mid;
-                        const float u = (q < 2) ? ((ci_ - sine * fj) - drow) : ((si_ + cosine * fj) - dcol);
-                        const bool dec = (q < 2) ? rdec : cdec;
-                        bool pred;
-                        if ((q & 1) == 0) pred = dec ? below_hi(u) : above_lo(u);
-                        else pred = dec ? !above_lo(u) : !below_hi(u);
-                        if (lo[q] < hi[q]) { if (pred) hi[q] = mid; else lo[q] = mid + 1; }
-                    }
+                const DescRowSearch rs = {sine, cosine, drow, dcol, t_hi, t_lo, __builtin_amdgcn_rcpf(sine), __builtin_amdgcn_rcpf(cosine), R, rdec, cdec};
+                bool bracket_ok = thr_ok;
+                if (thr_ok) {
+                    lo[0] = desc_row_flip<0>(rs, ci_, si_, bracket_ok); lo[1] = desc_row_flip<1>(rs, ci_, si_, bracket_ok);
+                    lo[2] = desc_row_flip<2>(rs, ci_, si_, bracket_ok); lo[3] = desc_row_flip<3>(rs, ci_, si_, bracket_ok);
+                }
+                if (__ballot(!bracket_ok)) {                          // wave uniform, rare: the bisection
+                    const int4 b4 = desc_row_bisect(rs, spacing, thr_ok, iters, ci_, si_);
+                    lo[0] = b4.x; lo[1] = b4.y; lo[2] = b4.z; lo[3] = b4.w;
                 }
             }
             const int jlo = max(max(lo[0], lo[2]), max(-R, -icol));

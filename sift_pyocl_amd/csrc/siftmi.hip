@@ -1375,7 +1375,9 @@ int siftmi_host_free(void *ptr) {
         const size_t bucket = it->second;
         hp.live.erase(it);
         std::vector<void *> &v = hp.spare[bucket];
-        if (v.size() < HostPool::kKeep) { v.push_back(ptr); return SIFTMI_OK; }
+        // (large blocks -- whole result images, record lists of dense frames -- are kept three deep: enough for a caller that
+        // drops each result before the next call, without parking hundreds of MB of page-locked memory)
+        if (v.size() < (bucket >= ((size_t)16 << 20) ? (size_t)3 : HostPool::kKeep)) { v.push_back(ptr); return SIFTMI_OK; }
     }
     (void)hipHostFree(ptr);
     return SIFTMI_OK;

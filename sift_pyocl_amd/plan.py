@@ -299,7 +299,18 @@ class SiftPlan(object):
                 total = C.c_int64(0)
                 _lib.check(L.siftmi_plan_records_device(self._handle, C.byref(C.c_void_p()), C.byref(total)))
                 count = total.value
-                output = numpy.empty(count, dtype=self.dtype_kp)
+                # Large lists too come back in a pinned block of the library's pool: a fresh numpy.empty of tens of MB is a
+                # new mmap on every call -- page faults under the DMA, the runtime registers the pages with the GPU for the
+                # copy, and when the caller drops the array the munmap invalidates that mapping, which stalls every queue of
+                # the process for 20-70 ms (measured in LinearAlign.align, round 4).  Pool blocks are recycled instead.
+                output = None
+                if self.pinned_results and count:
+                    try:
+                        output = _lib.pinned_empty(count, self.dtype_kp)
+                    except MemoryError:
+                        output = None
+                if output is None:
+                    output = numpy.empty(count, dtype=self.dtype_kp)
                 if count:
                     _lib.check(L.siftmi_plan_fetch(self._handle, output.ctypes.data, 0, 0, count))
             self._last_n = count

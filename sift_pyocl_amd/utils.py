@@ -35,7 +35,14 @@ def affine_least_squares(x, y, xp, yp):
     n = x.shape[0]
     mx, my = x.mean(), y.mean()
     xc = x - mx; yc = y - my
-    A = numpy.array([[xc.dot(xc), xc.dot(yc)], [xc.dot(yc), yc.dot(yc)]])
+
+    def dot(u, v):
+        # numpy's own pairwise summation, not BLAS ddot: a threaded BLAS wakes one worker per core for these 200 k-element
+        # products and lets them spin afterwards -- on the GPU box (256 logical CPUs) the next 20-70 ms of the process,
+        # its HIP submissions included, ran late (LinearAlign.align 103 ms with ddot, 55 ms without, round 4)
+        return float((u * v).sum())
+
+    A = numpy.array([[dot(xc, xc), dot(xc, yc)], [dot(xc, yc), dot(yc, yc)]])
     if n < 3 or abs(numpy.linalg.det(A)) <= 1e-12 * max(1.0, A[0, 0] * A[1, 1]):
         # degenerate geometry (collinear / too few points): fall back to the general solver
         X = numpy.zeros((2 * n, 6))
@@ -43,8 +50,8 @@ def affine_least_squares(x, y, xp, yp):
         X[1::2, 3] = x; X[1::2, 4] = y; X[1::2, 5] = 1
         rhs = numpy.zeros((2 * n,)); rhs[::2] = xp; rhs[1::2] = yp
         return numpy.linalg.lstsq(X, rhs, rcond=None)[0]
-    ab = numpy.linalg.solve(A, numpy.array([xc.dot(xp), yc.dot(xp)]))
-    de = numpy.linalg.solve(A, numpy.array([xc.dot(yp), yc.dot(yp)]))
+    ab = numpy.linalg.solve(A, numpy.array([dot(xc, xp), dot(yc, xp)]))
+    de = numpy.linalg.solve(A, numpy.array([dot(xc, yp), dot(yc, yp)]))
     c = xp.mean() - ab[0] * mx - ab[1] * my
     f = yp.mean() - de[0] * mx - de[1] * my
     return numpy.array([ab[0], ab[1], c, de[0], de[1], f])

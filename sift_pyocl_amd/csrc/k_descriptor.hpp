@@ -137,25 +137,29 @@ struct DescRowSearch {
     int R;
     bool rdec, cdec;
 };
-template <int Q>
-__device__ __forceinline__ bool desc_row_pred(const DescRowSearch &q, float ci_, float si_, int k) {
-    const float fj = (float)k;
-    const float u = (Q < 2) ? ((ci_ - q.sine * fj) - q.drow) : ((si_ + q.cosine * fj) - q.dcol);
-    const bool dec = (Q < 2) ? q.rdec : q.cdec;
-    // Q even: first jj inside the band; Q odd: first jj beyond it (thresholds verified by the caller: thr_ok)
-    if ((Q & 1) == 0) return dec ? (u < q.t_hi) : (u > q.t_lo);
-    return dec ? !(u > q.t_lo) : !(u < q.t_hi);
-}
-template <int Q>
-__device__ __forceinline__ int desc_row_flip(const DescRowSearch &q, float ci_, float si_, bool &ok) {
-    const bool dec = (Q < 2) ? q.rdec : q.cdec;
-    const float T = ((Q & 1) == 0) ? (dec ? q.t_hi : q.t_lo) : (dec ? q.t_lo : q.t_hi);
-    const float xs = (Q < 2) ? ((ci_ - q.drow) - T) * q.rsine : ((T + q.dcol) - si_) * q.rcosine;
+// flip q of 0..3 (0 / 1: entry into / exit from the row band, 2 / 3: the column band), all four through ONE copy of the code:
+// u = (A + B * jj) - D with (A, B, D) = (ci_, -sine, drow) or (si_, cosine, dcol) -- a - s * j == a + (-s) * j exactly --,
+// the threshold and the direction of the comparison picked by wave-uniform selects (a loop the compiler must not unroll:
+// four inlined copies held enough registers to push loop-invariant values of the kernel into scratch)
+__device__ __forceinline__ int desc_row_flip(const DescRowSearch &q, int which, float ci_, float si_, bool &ok) {
+    const bool col = which >= 2, odd = which & 1;
+    const bool dec = col ? q.cdec : q.rdec;
+    const float A = col ? si_ : ci_, B = col ? q.cosine : -q.sine, D = col ? q.dcol : q.drow;
+    // even: first jj inside the band (dec: u < t_hi, else u > t_lo); odd: first jj beyond it (dec: !(u > t_lo), else !(u < t_hi))
+    const bool use_hi = (dec != odd);                        // which threshold the comparison is against
+    const float T = use_hi ? q.t_hi : q.t_lo;
+    const float xs = col ? ((T + q.dcol) - si_) * q.rcosine : ((ci_ - q.drow) - T) * q.rsine;
     // (a NaN / infinite estimate lands anywhere in the clamp range: the step test below decides)
     const int k0 = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(xs) - 1.0f, (float)(-q.R - 2)), (float)(q.R - 2));
+    auto at = [&](int e) {
+        const int k = k0 + e;
+        const float u = (A + B * (float)k) - D;
+        // u < t_hi (even, dec) | u > t_lo (even, !dec) | !(u > t_lo) (odd, dec) | !(u < t_hi) (odd, !dec)
+        const bool cmp = use_hi ? (u < T) : (u > T);
+        return (k > q.R) || (k >= -q.R && (cmp != odd));
+    };
     // monotone false -> true: the flip is k0 + 1 + (number of false among positions 1 and 2), provided position 0 is false and
     // position 3 true (otherwise the flip lies outside the four positions: no claim)
-    auto at = [&](int e) { const int k = k0 + e; return (k > q.R) || (k >= -q.R && desc_row_pred<Q>(q, ci_, si_, k)); };
     int f = k0 + 1;
     ok = ok && !at(0);
     f += at(1) ? 0 : 1;
@@ -163,7 +167,6 @@ __device__ __forceinline__ int desc_row_flip(const DescRowSearch &q, float ci_, 
     ok = ok && at(3);
     return f;
 }
-
 
 // The bisection the bracket replaces: exact for any row, used where the thresholds could not be verified (thr_ok false: the
 // predicates then evaluate g(u) = u / spacing + 1.5f itself) or a lane's bracket found no step.  Not inlined: it runs for
@@ -527,11 +530,15 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
             const int ii = r - R;
             const float fi = (float)ii;
             const float ci_ = cosine * fi, si_ = sine * fi;
-            int lo[4];
+            int lo[4] = {0, 0, 0, 0};
             bool bracket_ok = thr_ok;
             if (thr_ok) {                                // wave uniform
-                lo[0] = desc_row_flip<0>(rs, ci_, si_, bracket_ok); lo[1] = desc_row_flip<1>(rs, ci_, si_, bracket_ok);
-                lo[2] = desc_row_flip<2>(rs, ci_, si_, bracket_ok); lo[3] = desc_row_flip<3>(rs, ci_, si_, bracket_ok);
+#pragma unroll 1
+                for (int which = 0; which < 4; which++) {            // (no lo[which]: a run-time register index)
+                    const int f = desc_row_flip(rs, which, ci_, si_, bracket_ok);
+                    lo[0] = which == 0 ? f : lo[0]; lo[1] = which == 1 ? f : lo[1];
+                    lo[2] = which == 2 ? f : lo[2]; lo[3] = which == 3 ? f : lo[3];
+                }
             }
             if (__ballot(!bracket_ok)) {                 // wave uniform, rare: the bisection (exact for every lane)
                 const int4 b4 = desc_row_bisect(rs, spacing, thr_ok, iters, ci_, si_);
@@ -695,8 +702,12 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
                 const DescRowSearch rs = {sine, cosine, drow, dcol, t_hi, t_lo, __builtin_amdgcn_rcpf(sine), __builtin_amdgcn_rcpf(cosine), R, rdec, cdec};
                 bool bracket_ok = thr_ok;
                 if (thr_ok) {
-                    lo[0] = desc_row_flip<0>(rs, ci_, si_, bracket_ok); lo[1] = desc_row_flip<1>(rs, ci_, si_, bracket_ok);
-                    lo[2] = desc_row_flip<2>(rs, ci_, si_, bracket_ok); lo[3] = desc_row_flip<3>(rs, ci_, si_, bracket_ok);
+#pragma unroll 1
+                    for (int which = 0; which < 4; which++) {
+                        const int f = desc_row_flip(rs, which, ci_, si_, bracket_ok);
+                        lo[0] = which == 0 ? f : lo[0]; lo[1] = which == 1 ? f : lo[1];
+                        lo[2] = which == 2 ? f : lo[2]; lo[3] = which == 3 ? f : lo[3];
+                    }
                 }
                 if (__ballot(!bracket_ok)) {                          // wave uniform, rare: the bisection
                     const int4 b4 = desc_row_bisect(rs, spacing, thr_ok, iters, ci_, si_);

@@ -113,7 +113,11 @@ struct Options {
     int maps_blocks = 8192;  // workgroups of gradient_maps_kernel (grid stride over 256 x 32 pixel items)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
-    int desc_sort = 16384;   // groups of at most this many oriented keypoints (<= 16384) are described largest window first (0: list order)
+    int desc_sort = 0;       // groups of at most this many oriented keypoints (<= 16384) are described largest window first (0: list order).
+                             // Round 3 (16384): headline 0.818 -> 0.809 ms; round 4, after the descriptor kernel's per-keypoint set-up was
+                             // cut: list order 0.802-0.809 against 0.811-0.815 ordered (three interleaved A/B runs; 9 octaves 0.961 / 0.969,
+                             // 2048^2 equal) -- the later octaves' chain ends the frame, the order only shortens the other one, and the
+                             // counting sort sits on the critical path; neighbours in the list share their window pixels in the caches
     int desc_sort_density = 600;   // ... and only with fewer keypoints than one per this many pixels of octave 0
     int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
     int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)

@@ -7,7 +7,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined"
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-steady"      # the headline workload only: 12 images
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o pmc --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o pmc --output-format csv -- $CMD > /dev/null 2> $OUT/write.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r03
 # -> gpurun_out/round_<tag>/ ; copy what should be judged into profiles/<tag>/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -20,8 +20,14 @@ python tools/dev/quick_smooth.py > $OUT/configs.txt 2>&1
 python tools/dev/small_frames.py tail 1 0 sizes=256,512,1024,2048 > $OUT/small_frames.txt 2>&1
 python tools/dev/small_frames.py tail 1 sizes=512,1024,2048 kind=smooth >> $OUT/small_frames.txt 2>&1
 bash tools/dev/trace_small.sh 512 > $OUT/timeline_white512.txt 2>&1
+bash tools/valu_frame.sh $OUT > $OUT/valu_frame.log 2>&1                       # VALU instructions per frame by kernel family and op class
+./tools/ubench/valu_rate_bench > $OUT/valu_issue_rate.txt 2>&1                 # issue interval per op class (tools/ubench/valu_rate.hip)
+python tools/bench_align.py > $OUT/bench_align.json 2>> $OUT/bench.err
+# one kernel-stats summary per bench leg (the driver's line carries all of them; their kernels must not blend)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt_c3 -o kt --output-format csv -- python $R/bench.py --size 16384 --octaves 0 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-steady > $OUT/bench_c3_16384.json 2>> $OUT/bench.err )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt_c4 -o kt --output-format csv -- python $R/bench.py --config c4 --steps 3 --warmup 1 > $OUT/bench_c4.json 2>> $OUT/bench.err )
+for leg in c3 c4; do f=$(ls $OUT/kt_$leg/*/*kernel_stats.csv $OUT/kt_$leg/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/rocprofv3_kernel_stats_$leg.csv; rm -rf $OUT/kt_$leg; done
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --config c4 --steps 5 --warmup 2 > $OUT/bench_c4.json 2>> $OUT/bench.err
 ls -la $OUT
 # keep what travels back small (gpurun merges at most 64 MiB): the raw CSVs stay on the box
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_* gpurun_out/trace_gaps

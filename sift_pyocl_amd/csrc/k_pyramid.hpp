@@ -25,7 +25,18 @@ __global__ void minmax_init(uint32_t *mm) { mm[0] = 0xffffffffu; mm[1] = 0u; }
 
 // Global min / max of an f32 image (replaces max_min_global_stage1/2, reductions.cl:62-199).
 // min/max are order independent, so any reduction tree gives the reference's bits.
-__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ img, int64_t n, uint32_t *mm) {
+// `reset` (may be null): the counter block of the NEXT image, zeroed here by workgroup 0 except word `reset_ones`, which becomes
+// 0xffffffff (the order-encoded +inf of its min slot).  The plan alternates between two counter blocks, so the image that is
+// running never touches the block being reset, and the per-image begin_image launch of rounds 1-3 (3.5 us + an 8 us gap in
+// front of this kernel, profiles/r04/timeline_white4096.txt) is gone.
+__device__ __forceinline__ void minmax_reset_next(uint32_t *reset, int reset_words, int reset_ones) {
+    if (reset && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < reset_words; i += blockDim.x) reset[i] = (i == reset_ones) ? 0xffffffffu : 0u;
+}
+
+__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ img, int64_t n, uint32_t *mm, uint32_t *reset = nullptr,
+                                                     int reset_words = 0, int reset_ones = -1) {
+    minmax_reset_next(reset, reset_words, reset_ones);
     float lo = __builtin_inff(), hi = -__builtin_inff();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,7 +137,9 @@ __device__ __forceinline__ void typed_chunk_minmax(const uint4 (&w)[TypedChunk<D
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void minmax_typed_kernel(const void *__restrict__ img, int64_t n, uint32_t *mm) {
+__global__ __launch_bounds__(256) void minmax_typed_kernel(const void *__restrict__ img, int64_t n, uint32_t *mm, uint32_t *reset = nullptr,
+                                                           int reset_words = 0, int reset_ones = -1) {
+    minmax_reset_next(reset, reset_words, reset_ones);
     using C = TypedChunk<DT>;
     float lo = __builtin_inff(), hi = -__builtin_inff();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

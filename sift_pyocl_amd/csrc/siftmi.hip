@@ -190,6 +190,8 @@ struct siftmi_plan {
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
     void *raw = nullptr;          // host-input staging (any dtype)
     int raw_dtype = -1;           // dtype of the image currently staged in `raw` (-1: none)
+    Counters *cnt_pair = nullptr;  // the two counter blocks (`cnt` points at the one of the image in flight)
+    int cnt_parity = 0;
     hipStream_t fin = nullptr;    // stream on which the last enqueued image ends
     int last_group0 = 0;          // oriented keypoints of octave 0 in the previous image (occupancy heuristic)
     int last_group1 = 0;          // ... of the later octaves
@@ -778,8 +780,9 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc) rc = p->alloc(&p->raw, N * (dtype_size(in_dtype) > 4 ? dtype_size(in_dtype) : 4));
     if (!rc && in_dtype != SIFTMI_F32) rc = p->alloc(&p->conv, N * sizeof(float));
 
-    if (!rc) rc = p->alloc(&p->cnt, sizeof(Counters));
-    if (!rc) p->mm = p->cnt->mm;   // device address of the min/max slots inside the counter block
+    // two counter blocks, used by alternate images: the min/max pass of an image resets the other one for its successor
+    if (!rc) rc = p->alloc(&p->cnt_pair, 2 * sizeof(Counters));
+    if (!rc) { p->cnt = p->cnt_pair; p->mm = p->cnt->mm; }   // (mm: device address of the min/max slots inside the counter block)
     if (!rc) rc = p->alloc(&p->cand, (size_t)p->kpsize * sizeof(float4));
     // a tail octave (<= SIFT_TAIL_MAX_PIXELS samples, 3 scales) cannot hold more candidates than this
     p->tail_cand_cap = (int)std::min<int64_t>(p->kpsize, 3 * SIFT_TAIL_MAX_PIXELS);
@@ -791,7 +794,11 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     if (!rc) rc = p->alloc(&p->order, (size_t)p->kpsize * sizeof(int));
     if (!rc) rc = p->alloc(&p->records, (size_t)p->kpsize * sizeof(KpRecord));
     if (!rc) rc = compute_schedule(p);
-    if (!rc && hipMemset(p->cnt, 0, sizeof(Counters)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipMemset failed");
+    if (!rc) {
+        hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt_pair);
+        hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt_pair + 1);
+        if (hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "counter initialisation failed");
+    }
     if (!rc) { hipEventCreate(&p->ev_first); hipEventCreate(&p->ev_last); hipEventCreate(&p->ev_last_b); }
     if (rc) { std::string keep = g_err; siftmi_plan_destroy(p); g_err = keep; return rc; }
     *out = p;
@@ -933,7 +940,14 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
     apply_ablate();
 #endif
     if (p->profile > 1) hipEventRecord(p->ev_first, p->stream);     // (light profile: only the blur bracket -- every event record between kernels is a bubble)
-    hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt);
+    // this image's counter block was reset by the min/max pass of the previous image (or at plan creation); the other block
+    // is reset by this image's min/max pass (k_pyramid.hpp: minmax_reset_next)
+    p->cnt = p->cnt_pair + p->cnt_parity;
+    p->mm = p->cnt->mm;
+    Counters *next_cnt = p->cnt_pair + (p->cnt_parity ^ 1);
+    p->cnt_parity ^= 1;
+    constexpr int kCntWords = (int)(sizeof(Counters) / 4), kCntOnes = (int)(offsetof(Counters, mm) / 4);
+    static_assert(sizeof(Counters) % 4 == 0, "Counters is a block of 32-bit words");
     const float *f32src = (const float *)src;
     // Typed frames (u8 / u16 / ... / RGB8) are converted at the point of use by the min/max and the initial blur
     // (or the plain normalise) -- no f32 copy of the frame in HBM.  Fallback to the convert pass: float64 frames,
@@ -961,10 +975,10 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
         Scope sc(p, "max_min");
         if (fused_in) {
             SIFTMI_TYPED_DISPATCH(image_dtype, hipLaunchKernelGGL(minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, mm_blocks)),
-                                                                   dim3(256), 0, p->stream, src, (int64_t)N, p->mm));
+                                                                   dim3(256), 0, p->stream, src, (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes));
         } else {
             hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, mm_blocks)), dim3(256), 0, p->stream, f32src,
-                               (int64_t)N, p->mm);
+                               (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes);
         }
     }
     float *base0 = p->plane(0, 0);

@@ -9,8 +9,8 @@ import csv, glob
 f = glob.glob("gpurun_out/trace_gaps/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last image = from the last begin_image_kernel
-idx = max(i for i, r in enumerate(rows) if "begin_image" in r["Kernel_Name"])
+# last image = from the last min/max pass (the first kernel of an image)
+idx = max(i for i, r in enumerate(rows) if "minmax" in r["Kernel_Name"])   # (round 4: no begin_image launch any more)
 t0 = int(rows[idx]["Start_Timestamp"])
 prev_end = t0
 for r in rows[idx:]:

@@ -20,7 +20,7 @@ python - <<PY
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/ts/*kernel_trace.csv")[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = max(i for i, r in enumerate(rows) if "begin_image" in r["Kernel_Name"])
+idx = max(i for i, r in enumerate(rows) if "minmax" in r["Kernel_Name"])   # (round 4: no begin_image launch any more)
 t0 = int(rows[idx]["Start_Timestamp"])
 for r in rows[idx:]:
     s = int(r["Start_Timestamp"]) - t0; e = int(r["End_Timestamp"]) - t0

@@ -6,6 +6,7 @@
 // order -- this file must be compiled with -ffp-contract=off.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace siftk {
@@ -814,6 +815,218 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
     }
 #undef VPASS
 }
+
+#ifdef SIFT_DEV_VARIANTS
+// ------------------------------------------------------------------------------------------
+// DEVELOPMENT BUILDS ONLY (SIFT_DEV_VARIANTS; option "glds").  Measured on a 4096^2 plane, bit-identical to blur_team_kernel:
+// 37.6 / 42.7 / 44.0 / 50.0 / 64.6 us against 36.6 / 40.5 / 41.9 / 48.5 / 62.0 for 11 / 15 / 17 / 21 / 27 taps, whole call 0.806 against 0.793 ms
+// -- the staging it removes was the V team's, and the H team bounds a step; the registers it frees (11 taps: 96 -> 59 VGPRs, 15:
+// 124 -> 74) cannot be turned into occupancy because more, shorter segments cost more warm-up rows than the extra waves hide
+// (1280 / 1536 / 2048 workgroups: slower for every tap count).  With the runs issued by the H team: +13 %.
+// Marching blur, team form with LDS-DMA staging (round 4; plain f32 planes without normalisation: every launch of a large
+// octave but the initial one).  Same strips, segments, sub-blocks, H pass and V march as blur_team_kernel -- the same
+// arithmetic in the same order, bit-identical -- but the rows of a sub-block go from HBM straight into their LDS buffer:
+//   * `global_load_lds_dword`: the LDS destination of a wave-wide load is base + 4 * lane, the source address is per lane, so
+//     lane l of run j of row pair rp fetches (row 2 rp + (l & 1), column 32 j + (l >> 1)): one instruction fills 32 columns of
+//     the [row pair][column][row & 1] image the packed H pass reads -- no look-ahead registers, no ds_write pass, no staging
+//     VALU work, and the V team (whose 27 packed accumulators set the kernel's register count) stages nothing at all;
+//   * the V team issues the runs (the H team, 2N packed operations per row pair against 1.5N, is the one without time to spare:
+//     with the runs on the H team every launch was 13 % slower): after marching sub-block g - 1 it waits for the runs of g + 1,
+//     issued one step earlier, and issues those of g + 2 -- into a ring of FOUR buffers, because the H team may still be
+//     filtering g in the buffer next to it and a ring of three would hand out the one being marched;
+//   * barriers are raw `s_barrier` behind `s_waitcnt lgkmcnt(0)`: a __syncthreads() would also wait for the runs in flight.
+typedef __attribute__((address_space(3))) void blur_lds_void;
+typedef __attribute__((address_space(1))) const void blur_glb_void;
+__device__ __forceinline__ void blur_team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int N, int S, int HW = 2>
+__global__ __launch_bounds__(64 * HW + 128) void blur_glds_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          int W, int H, int nblocks, int last_subs, int rows_out,
+                                                          TapsArg<N> taps, float *__restrict__ next0) {
+    constexpr int NT = 128;                       // threads of the V team (2 columns each)
+    using G = March2Geom<N, NT, S>;
+    using SS = SubSplit<N, S>;
+    static_assert(N & 1, "marching blur needs an odd tap count");
+    constexpr int BUF = G::NPS * G::PITCH * 2;    // floats per LDS buffer
+    constexpr int NBUF = 4;
+    constexpr int JN = (G::COLS + 31) / 32;       // runs of 32 columns per row pair
+    extern __shared__ float4 smem4[];
+    float *sbase = reinterpret_cast<float *>(smem4);
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 64 * HW ? 1 : 0;
+    const int tid = role ? (int)threadIdx.x - 64 * HW : (int)threadIdx.x;
+    const int x0 = blockIdx.x * G::TX;
+    const int ys = blockIdx.y * rows_out;
+    const int yend = min(ys + rows_out, H);
+    const unsigned W4 = (unsigned)W * 4u;
+    auto exists = [&](int blk, int sub) { return blk < nblocks - 1 || (blk == nblocks - 1 && sub < last_subs); };
+
+    if (role == 0) {
+        // ================= H team: horizontal pass
+        auto hpass = [&](float *s, int np) {
+            for (int task = tid; task < np * (NT / 2); task += 64 * HW) {
+                const int rp = task / (NT / 2), t4 = task % (NT / 2);
+                float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
+                f32x2 w[G::NW];
+                constexpr int PRE = 4;
+#pragma unroll
+                for (int k = 0; k < PRE && k < G::NW / 2; k++) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
+                    w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
+                }
+                f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < N; q++) {
+                    if ((q & 1) == 0) {
+                        const int k = q / 2 + PRE;
+                        if (k < G::NW / 2) {
+                            const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
+                            w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const float tp = taps.t[N - 1 - q];
+                    const f32x2 tp2 = {tp, tp};
+                    a0 = a0 + w[q] * tp2;
+                    a1 = a1 + w[q + 1] * tp2;
+                    a2 = a2 + w[q + 2] * tp2;
+                    a3 = a3 + w[q + 3] * tp2;
+                }
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<f32x4 *>(rowp) = (f32x4){a0.x, a1.x, a0.y, a1.y};
+                *reinterpret_cast<f32x4 *>(rowp + 4) = (f32x4){a2.x, a3.x, a2.y, a3.y};
+            }
+        };
+        blur_team_barrier();                       // (the V team's prologue: sub-block 0 has landed)
+        int g = 0;
+        for (int blk = 0; blk < nblocks; blk++) {
+#pragma unroll
+            for (int sub = 0; sub < S; sub++) {
+                if (blk == nblocks - 1 && sub >= last_subs) break;      // workgroup uniform
+                hpass(sbase + (g % NBUF) * BUF, SS::pairs(sub));
+                blur_team_barrier();
+                g++;
+            }
+        }
+        return;
+    }
+
+    // ================= V team: vertical march, global stores
+    f32x2 acc[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = (f32x2){0.f, 0.f};
+    const int gxo = x0 + 2 * tid;
+    const bool vec_store = ((W & 1) == 0) && (gxo + 1 < W);
+    const int lane = tid & 63;
+    const int hw = __builtin_amdgcn_readfirstlane(tid >> 6);     // the two V waves share the runs (a scalar: the split is a scalar branch)
+    const unsigned lds0 = (unsigned)(uintptr_t)sbase;           // LDS byte address of the ring (low half of the generic address)
+    unsigned colb[JN];                        // byte offset of this lane's column in run j (reflected at the plane's edges)
+    bool colv[JN];                            // the run's tail beyond the strip's last halo column is not loaded
+#pragma unroll
+    for (int j = 0; j < JN; j++) {
+        const int col = 32 * j + (lane >> 1);
+        colv[j] = col < G::COLS;
+        colb[j] = 4u * (unsigned)reflect_index(x0 - G::C + min(col, G::COLS - 1), W);
+    }
+    // one straight-line copy of the runs per V wave (HWC = the wave: a branch per run costs more than the run)
+    auto issue_wave = [&](auto HWC, int blk, int sub, int buf) {
+        constexpr int hwc = decltype(HWC)::value;
+        const int np = SS::pairs(sub);        // (sub is a compile-time value at every call)
+        const int v0 = ys - G::C + blk * N + sub * SS::RB;
+#pragma unroll
+        for (int rp = 0; rp < G::NPS; rp++) {
+            if (rp < np) {
+                const unsigned r0 = (unsigned)reflect_index(v0 + 2 * rp, H) * W4, r1 = (unsigned)reflect_index(v0 + 2 * rp + 1, H) * W4;
+                const unsigned rowb = (lane & 1) ? r1 : r0;
+#pragma unroll
+                for (int j = 0; j < JN; j++) {
+                    if ((rp * JN + j) % 2 == hwc) {
+                        // (the LDS address as an integer: a cast of the generic pointer costs a null test per run)
+                        const unsigned dst = lds0 + 4u * (unsigned)(buf * BUF + (rp * G::PITCH + 32 * j) * 2);
+                        if (32 * j + 32 <= G::COLS || colv[j])            // only the last run has lanes beyond the strip's halo
+                            __builtin_amdgcn_global_load_lds((blur_glb_void *)(reinterpret_cast<const char *>(in) + (rowb + colb[j])),
+                                                             reinterpret_cast<blur_lds_void *>((uintptr_t)dst), 4, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    auto issue = [&](int blk, int sub, int buf) {
+        if (hw == 0) issue_wave(std::integral_constant<int, 0>{}, blk, sub, buf);
+        else issue_wave(std::integral_constant<int, 1>{}, blk, sub, buf);
+    };
+#define VPASS(sbuf, blk_, sub_)                                                                              \
+    {                                                                                                        \
+        const int np_ = SS::pairs(sub_), nrows_ = SS::rows(sub_);                                            \
+        const int ybase_ = ys + (blk_) * N - (N - 1);                                                        \
+        float *optr = out + ((ptrdiff_t)(ybase_ + (sub_) * SS::RB) * W + gxo);                              \
+        f32x4 hv_next = *reinterpret_cast<const f32x4 *>((sbuf) + (2 * tid) * 2);                           \
+        _Pragma("unroll") for (int rp = 0; rp < G::NPS; rp++) {                                              \
+            if (rp < np_) {                                                                                  \
+                const f32x4 hv = hv_next;                                                                    \
+                if (rp + 1 < np_) hv_next = *reinterpret_cast<const f32x4 *>((sbuf) + ((rp + 1) * G::PITCH + 2 * tid) * 2); \
+                __builtin_amdgcn_sched_barrier(0);                                                           \
+                _Pragma("unroll") for (int half = 0; half < 2; half++) {                                     \
+                    if (2 * rp + half < nrows_) {                                                            \
+                        const int kk = (sub_) * SS::RB + 2 * rp + half;                                      \
+                        const f32x2 h = half ? hv.zw : hv.xy;                                                \
+                        _Pragma("unroll") for (int k = 0; k < (N + 1) / 2; k++) {                            \
+                            const f32x2 t2 = {taps.t[k], taps.t[k]};                                         \
+                            const f32x2 prod = h * t2;                                                       \
+                            const int slot_a = (kk - k + N) % N, slot_b = (kk - (N - 1 - k) + N) % N;        \
+                            if (k == 0) acc[slot_a] = (f32x2){0.f, 0.f} + prod;                              \
+                            else acc[slot_a] = acc[slot_a] + prod;                                           \
+                            asm volatile("" : "+v"(acc[slot_a]));                                            \
+                            if (k != N - 1 - k) { acc[slot_b] = acc[slot_b] + prod; asm volatile("" : "+v"(acc[slot_b])); } \
+                        }                                                                                    \
+                        const int done = (kk + 1) % N;                                                       \
+                        const int y = ybase_ + kk;                                                           \
+                        if (y >= ys && y < yend) {                                                           \
+                            if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];                     \
+                            else { if (gxo < W) optr[0] = acc[done].x; if (gxo + 1 < W) optr[1] = acc[done].y; } \
+                            if (next0 && !(y & 1) && (y >> 1) < (H >> 1) && (gxo >> 1) < (W >> 1))           \
+                                next0[(size_t)(y >> 1) * (W >> 1) + (gxo >> 1)] = acc[done].x;              \
+                        }                                                                                    \
+                        optr += W;                                                                           \
+                    }                                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+    // prologue: sub-block 0 lands, sub-block 1 is in flight
+    issue(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (S > 1) { if (exists(0, 1 % S)) issue(0, 1 % S, 1); }
+    else if (exists(1, 0)) issue(1, 0, 1);
+    blur_team_barrier();
+    int g = 0;
+    for (int blk = 0; blk < nblocks; blk++) {
+#pragma unroll
+        for (int sub = 0; sub < S; sub++) {
+            if (blk == nblocks - 1 && sub >= last_subs) break;      // workgroup uniform
+            if (g > 0) {
+                float *prev = sbase + ((g + NBUF - 1) % NBUF) * BUF;
+                if (sub == 0) { VPASS(prev, blk - 1, S - 1) } else { VPASS(prev, blk, (sub + S - 1) % S) }
+            }
+            // the runs of step g + 1, issued a step ago, have landed (the wait also covers this step's stores: the V team is
+            // the one with time to spare); then those of step g + 2 go out
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int sub2 = (sub + 2) % S, blk2 = blk + (sub + 2) / S;
+            if (exists(blk2, sub2)) issue(blk2, sub2, (g + 2) % NBUF);
+            blur_team_barrier();
+            g++;
+        }
+    }
+    {
+        float *prev = sbase + ((g + NBUF - 1) % NBUF) * BUF;
+        if (last_subs >= S) { VPASS(prev, nblocks - 1, S - 1) }
+        if constexpr (S > 1) { if (last_subs == 1) { VPASS(prev, nblocks - 1, 0) } }
+        if constexpr (S > 2) { if (last_subs == 2) { VPASS(prev, nblocks - 1, 1) } }
+        if constexpr (S > 3) { if (last_subs == 3) { VPASS(prev, nblocks - 1, 2) } }
+    }
+#undef VPASS
+}
+
+#endif  // SIFT_DEV_VARIANTS
 
 // Generic (any tap count, incl. even sizes) two-pass blur: plain global loads, used only for
 // non-default init_sigma schedules and stage replay.  Same arithmetic.

@@ -144,6 +144,7 @@ struct Options {
     int ori_small_blocks = 608;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints (512 until the descriptor launch was ordered: 0.809 ms; 576-640: 0.799-0.801; 704: 0.813)
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
+    int glds = 0;            // development builds: LDS-DMA staging in the team blur of large planes (blur_glds_kernel; measured 3-5 % slower)
     int tail_fault = 0;      // diagnostic: the next `tail_fault` images that go through octave_tail_kernel are treated as if a
                              // workgroup of it had timed out (exercises the host's re-run path; results do not change)
 };
@@ -345,6 +346,15 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
     while (covered(b, m) < need) m++;                // m <= S
     const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
     dim3 grid((unsigned)gx, (unsigned)gy);
+#ifdef SIFT_DEV_VARIANTS
+    if constexpr (!NORM && DT == 0) {
+        if (opt.glds) {            // LDS-DMA staging (k_pyramid.hpp: blur_glds_kernel), plain f32 planes without normalisation
+            hipLaunchKernelGGL((blur_glds_kernel<N, S>), grid, dim3(256), (size_t)4 * G::LDS_BYTES, st, (const float *)in, out, W, H, nblocks,
+                               last_subs, rows_out, ta, half);
+            return;
+        }
+    }
+#endif
     hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
                        rows_out, ta, mm, half);
 }
@@ -906,6 +916,9 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else if (n == "tail_fault") o.tail_fault = v > 0 ? v : 0;
+#ifdef SIFT_DEV_VARIANTS
+    else if (n == "glds") o.glds = v != 0;
+#endif
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
     return SIFTMI_OK;
 }

@@ -22,17 +22,27 @@ def main():
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
-    assert torch.cuda.device_count() >= world, "one GPU per rank"
-    torch.cuda.set_device(local)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    assert dist.get_world_size() == world and dist.get_backend() == "nccl"
+    # SIFT_MULTI_REHEARSAL=1: every rank on cuda:0 with the collectives over gloo (RCCL refuses two ranks on one device) --
+    # the one-GPU rehearsal of this very script; the exchange then takes the host-staged path of batch.keypoints_batch
+    rehearsal = os.environ.get("SIFT_MULTI_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"                      # the plans pick their device from it
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo")
+    else:
+        assert torch.cuda.device_count() >= world, "one GPU per rank"
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    backend = dist.get_backend()
+    assert dist.get_world_size() == world and backend == ("gloo" if rehearsal else "nccl")
     import sift_pyocl_amd as sp
     from sift_pyocl_amd import batch
     from util import sort_kp, sort_rows
 
     size, n_frames = 1024, 2 * world + 1                  # an uneven split: rank 0 owns one frame more
     frames = [torch.from_numpy(np.random.default_rng(100 + i).random((size, size), dtype=np.float32)).cuda() for i in range(n_frames)]
-    got = batch.keypoints_batch(frames, device=local)
+    got = batch.keypoints_batch(frames)
     single = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local)
     exp = single.keypoints_batch(frames)
     assert len(got) == n_frames
@@ -40,7 +50,7 @@ def main():
         assert len(got[i]) == len(exp[i]) > 100, (rank, i, len(got[i]), len(exp[i]))
         assert sort_kp(got[i]).tobytes() == sort_kp(exp[i]).tobytes(), "frame %d differs on rank %d" % (i, rank)
     # fewer frames than ranks: the last rank owns nothing
-    few = batch.keypoints_batch(frames[:world - 1], device=local) if world > 1 else []
+    few = batch.keypoints_batch(frames[:world - 1]) if world > 1 else []
     for i in range(world - 1):
         assert sort_kp(few[i]).tobytes() == sort_kp(exp[i]).tobytes()
     # MatchPlan sharded by query
@@ -52,7 +62,7 @@ def main():
     assert np.array_equal(sort_rows(np.asarray(pairs)), sort_rows(np.asarray(whole)))
     dist.barrier()
     if rank == 0:
-        print("multi ok: %d ranks over nccl, %d frames, %d pairs" % (world, n_frames, len(pairs)), flush=True)
+        print("multi ok: %d ranks over %s, %d frames, %d pairs" % (world, backend, n_frames, len(pairs)), flush=True)
     dist.destroy_process_group()
 
 

@@ -44,13 +44,28 @@ def bench(args, timeout=900):
     return json.loads(lines[0])
 
 
+def run_worker(extra_env, port):
+    e = env()
+    e.update(extra_env)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), os.path.join("tests", "multi_worker.py")], cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True, env=e)
+
+
 @needs_two
 def test_sharded_paths_over_rccl_equal_one_rank():
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29547", os.path.join("tests", "multi_worker.py")], cwd=ROOT,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True, env=env())
+    out = run_worker({}, 29547)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert "multi ok: 2 ranks over nccl" in out.stdout
+
+
+def test_worker_rehearsal_on_one_gpu():
+    """The same worker script with both ranks on cuda:0 and gloo collectives: what can be checked of it on a one-GPU box
+    (its frame / shard / match logic and the host-staged exchange), so that the RCCL run above does not meet the script
+    for the first time on the day a second GPU appears."""
+    out = run_worker({"SIFT_MULTI_REHEARSAL": "1"}, 29548)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert "multi ok: 2 ranks over gloo" in out.stdout
 
 
 @needs_two

@@ -86,7 +86,7 @@ int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsiz
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
- *   launch shapes      "march", "team", "march_nt", "march_wgs", "march_nb", "tile", "mm_blocks", "ext_rows", "ext_strips",
+ *   launch shapes      "march", "team", "march_nt", "march_wgs", "march_nb", "tile", "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
  *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks",
  *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_sort", "desc_sort_density",
  *                      "desc_stream", "maps_blocks"

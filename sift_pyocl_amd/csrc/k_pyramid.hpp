@@ -35,8 +35,11 @@ __device__ __forceinline__ void minmax_reset_next(uint32_t *reset, int reset_wor
         for (int i = threadIdx.x; i < reset_words; i += blockDim.x) reset[i] = (i == reset_ones) ? 0xffffffffu : 0u;
 }
 
-__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ img, int64_t n, uint32_t *mm, uint32_t *reset = nullptr,
-                                                     int reset_words = 0, int reset_ones = -1) {
+// Workgroups of 256 or 1024 threads (blockDim): the pass is a latency-bound stream -- 256 workgroups of four waves are one wave
+// per SIMD (3.5 TB/s), and more workgroups pay for their two same-address atomics (8-10 ns each, served one at a time);
+// sixteen waves per workgroup give four waves per SIMD at the same 256 atomic pairs.
+__global__ __launch_bounds__(1024) void minmax_kernel(const float *__restrict__ img, int64_t n, uint32_t *mm, uint32_t *reset = nullptr,
+                                                      int reset_words = 0, int reset_ones = -1) {
     minmax_reset_next(reset, reset_words, reset_ones);
     float lo = __builtin_inff(), hi = -__builtin_inff();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -66,13 +69,13 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ i
         lo = fminf(lo, __shfl_xor(lo, off));
         hi = fmaxf(hi, __shfl_xor(hi, off));
     }
-    __shared__ float slo[4], shi[4];
-    const int wave = threadIdx.x >> 6;
+    __shared__ float slo[16], shi[16];
+    const int wave = threadIdx.x >> 6, nwaves = (int)blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) { slo[wave] = lo; shi[wave] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+        lo = slo[0]; hi = shi[0];
+        for (int w = 1; w < nwaves; w++) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
         if (lo <= hi) {   // skip all-NaN partials
             atomicMin(&mm[0], f2ord(lo));
             atomicMax(&mm[1], f2ord(hi));

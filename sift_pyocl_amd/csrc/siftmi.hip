@@ -112,6 +112,8 @@ struct Options {
     int maps = 2, maps_density = 200;
     int maps_blocks = 8192;  // workgroups of gradient_maps_kernel (grid stride over 256 x 32 pixel items)
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
+    int mm_threads = 1024;   // threads per workgroup of the f32 min/max pass: sixteen waves per workgroup = four per SIMD at the same 256 atomic pairs
+                             // (256 threads: one wave per SIMD; three interleaved A/B runs 0.7924-0.7934 -> 0.7863-0.7876 ms, 512^2 0.2561 -> 0.2531)
     int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
     int desc_sort = 0;       // groups of at most this many oriented keypoints (<= 16384) are described largest window first (0: list order).
                              // Round 3 (16384): headline 0.818 -> 0.809 ms; round 4, after the descriptor kernel's per-keypoint set-up was
@@ -887,6 +889,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_blocks must be >= 1"); o.desc_blocks = v; }
     else if (n == "desc_pad") o.desc_pad = v;
     else if (n == "desc_stream") o.desc_stream = v != 0;
+    else if (n == "mm_threads") { if (v != 256 && v != 512 && v != 1024) return fail(SIFTMI_EINVAL, "mm_threads must be 256, 512 or 1024"); o.mm_threads = v; }
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
     else if (n == "chain0") o.chain0 = v != 0;
     else if (n == "ori_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_small_blocks must be >= 1"); o.ori_small_blocks = v; }
@@ -990,7 +993,8 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
             SIFTMI_TYPED_DISPATCH(image_dtype, hipLaunchKernelGGL(minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, mm_blocks)),
                                                                    dim3(256), 0, p->stream, src, (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes));
         } else {
-            hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, mm_blocks)), dim3(256), 0, p->stream, f32src,
+            const int mm_threads = p->opt.mm_threads;
+            hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, mm_threads, mm_blocks)), dim3(mm_threads), 0, p->stream, f32src,
                                (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes);
         }
     }

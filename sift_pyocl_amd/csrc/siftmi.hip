@@ -37,6 +37,12 @@ namespace {
 
 thread_local std::string g_err;
 
+// Events that order one stream of a plan behind another ON THE SAME DEVICE: no timing, and no system-scope fence when they are
+// recorded (the kernels' own agent-scope release / acquire at their boundaries is what the consumers need; nothing the host or
+// another device reads is ordered by these events -- results are waited for through the streams themselves).
+#ifndef SIFT_SYNC_EVENT
+#define SIFT_SYNC_EVENT (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
 #define SIFTMI_ETAILRETRY (-100)   // internal: plan_wait -> siftmi_plan_keypoints, never returned through the C ABI
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -779,13 +785,13 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     }
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
-    if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&p->ev_grp1, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&p->ev_det, hipEventDisableTiming) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
+    if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, SIFT_SYNC_EVENT) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_grp1, SIFT_SYNC_EVENT) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_det, SIFT_SYNC_EVENT) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
     p->overlap = true;
     for (int o = 0; o < p->n_oct && !rc; o++) {
         hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
+        if (hipEventCreateWithFlags(&e, SIFT_SYNC_EVENT) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
         else p->ev_pyr.push_back(e);
     }
     if (!rc) rc = p->alloc(&p->tmp, N * sizeof(float));
@@ -1060,8 +1066,8 @@ int enqueue_body(siftmi_plan *p) {
         if (!p->stream4) HIPCHK(hipStreamCreateWithFlags(&p->stream4, hipStreamNonBlocking));
         while ((int)p->ev_kp.size() < nbands) {
             hipEvent_t a, b;
-            HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&a, SIFT_SYNC_EVENT));
+            HIPCHK(hipEventCreateWithFlags(&b, SIFT_SYNC_EVENT));
             p->ev_kp.push_back(a); p->ev_out.push_back(b);
         }
     }
@@ -1101,7 +1107,7 @@ int enqueue_body(siftmi_plan *p) {
             }
         }
         p->maps_g0 = want0; p->maps_g1 = want1; p->later_group = later;
-        if (want0 && two && !p->ev_maps0) HIPCHK(hipEventCreateWithFlags(&p->ev_maps0, hipEventDisableTiming));
+        if (want0 && two && !p->ev_maps0) HIPCHK(hipEventCreateWithFlags(&p->ev_maps0, SIFT_SYNC_EVENT));
     }
     auto pyramid_stream = [&](int oct) { return (chain0 && oct > 0) ? p->stream3 : p->stream; };                                   // builds an octave's planes
     // Later octaves: the pyramid of octave o+1 needs only plane 3 of octave o, not its detection.  With "split_detect" the
@@ -1114,7 +1120,7 @@ int enqueue_body(siftmi_plan *p) {
     // shrink + five blurs of one octave on its pyramid stream (once)
     hipEvent_t pyr0_done = nullptr;            // light profile: the blur bracket's closing event stands in for ev_pyr[0]
     const bool early0 = chain0 && p->opt.early_chain && p->n_oct > 1 && p->profile <= 1;
-    if (early0 && !p->ev_p3) HIPCHK(hipEventCreateWithFlags(&p->ev_p3, hipEventDisableTiming));
+    if (early0 && !p->ev_p3) HIPCHK(hipEventCreateWithFlags(&p->ev_p3, SIFT_SYNC_EVENT));
     auto build_pyramid = [&](int oct) -> int {
         if (built[oct]) return SIFTMI_OK;
         built[oct] = true;

@@ -454,45 +454,12 @@ __device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4
     w.interior = w.irow - R >= 1 && w.irow + R <= w.H - 2 && w.icol - R >= 1 && w.icol + R <= w.W - 2;
 }
 
-// `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
-// after that it asks the counter, so that a wave with a small window does not idle while another still has two large
-// ones to go (windows differ by 4x in samples within an octave).
+// One oriented keypoint (x, y, sigma*oct, angle), detection scale | octave << 8 in `aux`, described by the calling WAVE:
+// steps 1-4 of the file header; the record goes to `rec` (and `hrec`).  Everything about the keypoint is wave uniform.
 template <bool MAPS>
-__device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
-                                                 int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
-                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks,
-                                                 const int *__restrict__ order) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    DescRowLds &L = lds_all[wave];
-    siftmath::load_atan_fold(fold);
-    desc_pool_init(L.P, lane);
-    __syncthreads();                     // the only workgroup barrier: the fold table
-    const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
-    const DescRoute rt = desc_route_of(L.P, lane);
-    const float4 *pool4 = reinterpret_cast<const float4 *>(L.P.pool);
-
-    auto advance = [&](int i) {
-        if (!next) return i + nwaves;
-        int t = 0;
-        if (lane == 0) t = atomicAdd(next, 1);
-        return start + nwaves + __builtin_amdgcn_readfirstlane(t);
-    };
-    for (int t = start + gwave; t < end; t = advance(t)) {
-        // hand-out position t -> keypoint i: list order, or the order mark_group_kernel prepared (largest windows first)
-        const int i = order ? __builtin_amdgcn_readfirstlane(order[t]) : t;
-        // the keypoint is the same in every lane: keep its integer attributes in scalar registers
-        float4 kq = okp[i];              // (x, y, sigma*oct, angle)
-        kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
-        kq.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.y)));
-        kq.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.z)));
-        kq.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.w)));
-        const int aux = __builtin_amdgcn_readfirstlane(oaux[i]);         // detection scale | octave << 8
-        KpRecord *rec = records + i;
-        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
-        if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
-            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.P.pool));
-            continue;
-        }
+__device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const float4 kq, int aux, KpRecord *rec, KpRecord *hrec,
+                                              DescRowLds &L, const double *fold, const DescRoute &rt, const float4 *pool4, int lane) {
+    {
         DescWindow w;
         int R;
         desc_window<MAPS>(tab, kq, aux, w, R);
@@ -623,6 +590,109 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.P.pool));
     }
 }
+
+// `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
+// after that it asks the counter, so that a wave with a small window does not idle while another still has two large
+// ones to go (windows differ by 4x in samples within an octave).
+template <bool MAPS>
+__device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
+                                                 int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
+                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks,
+                                                 const int *__restrict__ order) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    DescRowLds &L = lds_all[wave];
+    siftmath::load_atan_fold(fold);
+    desc_pool_init(L.P, lane);
+    __syncthreads();                     // the only workgroup barrier: the fold table
+    const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
+    const DescRoute rt = desc_route_of(L.P, lane);
+    const float4 *pool4 = reinterpret_cast<const float4 *>(L.P.pool);
+
+    auto advance = [&](int i) {
+        if (!next) return i + nwaves;
+        int t = 0;
+        if (lane == 0) t = atomicAdd(next, 1);
+        return start + nwaves + __builtin_amdgcn_readfirstlane(t);
+    };
+    for (int t = start + gwave; t < end; t = advance(t)) {
+        // hand-out position t -> keypoint i: list order, or the order mark_group_kernel prepared (largest windows first)
+        const int i = order ? __builtin_amdgcn_readfirstlane(order[t]) : t;
+        // the keypoint is the same in every lane: keep its integer attributes in scalar registers
+        float4 kq = okp[i];              // (x, y, sigma*oct, angle)
+        kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
+        kq.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.y)));
+        kq.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.z)));
+        kq.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.w)));
+        const int aux = __builtin_amdgcn_readfirstlane(oaux[i]);         // detection scale | octave << 8
+        KpRecord *rec = records + i;
+        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
+        if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
+            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.P.pool));
+            continue;
+        }
+        desc_one_wave<MAPS>(tab, kq, aux, rec, hrec, L, fold, rt, pool4, lane);
+    }
+}
+
+#ifdef SIFT_DEV_VARIANTS
+// DEVELOPMENT BUILDS ONLY -- measured slower than the separate launches on every frame (Options::fused_kp in siftmi.hip).
+// Orientation AND description of refined keypoints by one wave each (keypoint_fused_kernel): a wave takes refined keypoint t,
+// assigns its orientations (orient_wave: at most 36, nearly always one or two), reserves that many record slots with one
+// atomic and describes them one after the other.  Nothing of a keypoint leaves its wave between the two steps: no oriented
+// list, no launch boundary (the orientation launch of the headline frame's octave 0 lasted 57 us for 25 us worth of
+// instructions -- a launch of short latency chains ends with its slowest wave -- and mark_group_kernel plus two dispatch
+// gaps followed it), no freezing of list ranges between the groups.  The orientation scratch lives in the value pool of the
+// descriptor's routing tables, which is free between two descriptors; the angles wait in its unused words [900, 936).
+template <bool MAPS>
+__device__ __forceinline__ void fused_waves(const OctaveTable &tab, float ori_sigma, const float4 *__restrict__ kp,
+                                            const int *__restrict__ kp_aux, int n, Counters *cnt, int group, int out_capacity,
+                                            KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
+                                            DescRowLds *lds_all, double *fold, int *next, int nblocks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    DescRowLds &L = lds_all[wave];
+    siftmath::load_atan_fold(fold);
+    desc_pool_init(L.P, lane);
+    __syncthreads();                     // the only workgroup barrier: the fold table
+    const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
+    const DescRoute rt = desc_route_of(L.P, lane);
+    const float4 *pool4 = reinterpret_cast<const float4 *>(L.P.pool);
+    OriWaveScratch &O = *reinterpret_cast<OriWaveScratch *>(L.P.pool);
+    static_assert(sizeof(OriWaveScratch) <= 896 * sizeof(float), "orientation scratch inside the value area of the pool");
+    float *peaks = &L.P.pool[900];
+
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    auto advance = [&](int i) {
+        if (!next) return i + nwaves;
+        int t = 0;
+        if (lane == 0) t = atomicAdd(next, 1);
+        return nwaves + __builtin_amdgcn_readfirstlane(t);
+    };
+    int made = 0;
+    for (int t = gwave; t < n; t = advance(t)) {
+        float4 k = kp[t];                // (peak, row, col, sigma)
+        k.x = uni(k.x); k.y = uni(k.y); k.z = uni(k.z); k.w = uni(k.w);
+        const int aux = __builtin_amdgcn_readfirstlane(kp_aux[t]);       // detection scale | octave << 8
+        if (!(k.y >= 0.0f)) continue;
+        float ox, oy, os;
+        const int np = __builtin_amdgcn_readfirstlane(orient_wave<MAPS>(tab, ori_sigma, k, aux, O, peaks, fold, lane, ox, oy, os));
+        if (np == 0) continue;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&cnt->n_out, np);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        made += np;
+        ox = uni(ox); oy = uni(oy); os = uni(os);
+#pragma unroll 1
+        for (int q = 0; q < np; q++) {
+            const int i = slot + q;
+            if (i >= out_capacity) { if (lane == 0) cnt->overflow = 1; break; }
+            const float4 kq = make_float4(ox, oy, os, uni(peaks[q]));
+            KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
+            desc_one_wave<MAPS>(tab, kq, aux, records + i, hrec, L, fold, rt, pool4, lane);
+        }
+    }
+    if (lane == 0 && made) atomicAdd(&cnt->grp_made[group], made);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same descriptor, ONE WORKGROUP (four waves) per keypoint: for sparse groups.  With a wave per keypoint a launch
@@ -835,5 +905,25 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
                          (cnt && order && cnt->grp_sorted[group]) ? order : nullptr);
     }
 }
+
+#ifdef SIFT_DEV_VARIANTS
+// kp / kp_aux: the GROUP's own refined list (cnt->kp_count[group] entries): with one list per group nothing has to be
+// frozen before the other chain appends.
+template <bool MAPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
+void keypoint_fused_kernel(OctaveTable tab, float ori_sigma, const float4 *__restrict__ kp, const int *__restrict__ kp_aux,
+                           Counters *cnt, int group, int kp_capacity, int out_capacity, KpRecord *__restrict__ records,
+                           KpRecord *host_records, int host_capacity, int dynamic, int dense_blocks, int small_blocks) {
+    __shared__ DescLds lds;
+    __shared__ double fold[36];
+    const int n_all = cnt->kp_count[group];
+    const int n = min(n_all, kp_capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_all > kp_capacity) cnt->overflow = 1;
+    const int nblocks = n >= 65536 ? min((int)gridDim.x, dense_blocks) : (n < 16384 ? min((int)gridDim.x, small_blocks) : (int)gridDim.x);
+    if ((int)blockIdx.x >= nblocks) return;
+    fused_waves<MAPS>(tab, ori_sigma, kp, kp_aux, n, cnt, group, out_capacity, records, host_records, host_capacity, lds.rows, fold,
+                      dynamic ? &cnt->desc_next[group] : nullptr, nblocks);
+}
+#endif
 
 }  // namespace siftk

@@ -77,6 +77,8 @@ struct Counters {
     int grp_out_start[SIFT_GROUPS + 1]; // record-list range of each group, closed by mark_group_kernel
     int grp_out_end[SIFT_GROUPS + 1];
     int n_cand[SIFT_MAX_OCTAVES];       // candidates per octave
+    int kp_count[2];                    // fused per-keypoint launches (keypoint_fused_kernel): refined keypoints of group 0 / of the later octaves, each group in its own list
+    int grp_made[2];                    // ... and the oriented keypoints each group has yielded
     uint32_t mm[2];                     // order-encoded min / max of the input (k_pyramid.hpp), read back with the counters
     int tail_ready[8];                  // octave_tail_kernel: plane 3 of tail octave k is in HBM (k_tail.hpp)
     int desc_next[SIFT_GROUPS + 1];     // descriptor_kernel: keypoints of the group handed out beyond every wave's first one
@@ -472,6 +474,163 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         store_pending(slot, pending);
     }
 }
+
+#ifdef SIFT_DEV_VARIANTS
+// ------------------------------------------------------------------------------------------
+// The orientation assignment of ONE refined keypoint by the calling wave, for the kernel that orients and describes a
+// keypoint in one go (k_descriptor.hpp: keypoint_fused_kernel): the same votes, the same ordered sums, the same smoothing
+// and peak rules as orientation_kernel above (wave-per-keypoint form).  The keypoint is wave uniform: k = (peak, row, col,
+// sigma), aux = detection scale | octave << 8.  The angles of the oriented keypoints it yields go to peaks[0 .. n) (LDS),
+// n is returned, (ox, oy, os) are the record's x, y and scale.
+struct alignas(16) OriWaveScratch {
+    float pool[64 + 36 * 3 + 4];   // 64 values, every bin's segment padded to a multiple of 4
+    uint2 mask[36];
+    unsigned mbase[36];
+};
+template <bool MAPS>
+__device__ __forceinline__ int orient_wave(const OctaveTable &tab, float ori_sigma, const float4 k, int aux, OriWaveScratch &L,
+                                           float *peaks, const double *fold, int lane, float &ox, float &oy, float &os) {
+    const int scale = aux & 0xff, oct = aux >> 8;
+    const int W = tab.W[oct], H = tab.H[oct], octsize = 1 << oct;
+    const float *I = tab.base + tab.off[oct] + (size_t)scale * W * H;
+    const float *Gm = MAPS ? tab.gmap + map_offset(tab, oct, scale) : nullptr;
+    const float *Om = MAPS ? tab.omap + map_offset(tab, oct, scale) : nullptr;
+    auto taps_at = [&](int x, int y) {
+        if (!MAPS) return gradient_fetch(I, x, y, W, H);
+        GradTaps t = {};
+        const size_t pos = (size_t)y * W + x;
+        t.xa = Gm[pos]; t.xb = Om[pos];          // (magnitude, orientation)
+        return t;
+    };
+    const float4 *pool4 = reinterpret_cast<const float4 *>(L.pool);
+    if (lane < 36) L.mask[lane] = make_uint2(0u, 0u);        // (the scratch area is the descriptor's value pool between two keypoints)
+    __builtin_amdgcn_wave_barrier();
+    const int row = (int)((double)k.y + 0.5), col = (int)((double)k.z + 0.5);
+    const float sigma = ori_sigma * k.w;
+    const int radius = (int)((double)sigma * 3.0);
+    const int rmin = max(0, row - radius), cmin = max(0, col - radius);
+    const int rmax = min(row + radius, H - 2), cmax = min(col + radius, W - 2);
+    const float lim = (float)(radius * radius) + 0.5f;
+    const float two_s2 = 2.0f * sigma * sigma;
+    const float r_two_s2 = 1.0f / two_s2;
+    const bool fast_div = two_s2 >= 1e-3f && two_s2 <= 1e6f;
+    const int wc = cmax - cmin + 1, hr = rmax - rmin + 1;
+    const int total = (wc > 0 && hr > 0) ? wc * hr : 0;
+    const float inv_wc = 1.0f / (float)max(wc, 1);
+    float h = 0.0f;                  // lane b < 36 owns hist[b]
+    auto locate = [&](int base, int &r, int &c) {
+        const int idx = base + lane;
+        if (idx >= total) return false;
+        int rem;
+        const int q = div_exact(idx, wc, inv_wc, rem);
+        r = rmin + q; c = cmin + rem;
+        return true;
+    };
+    int nr = 0, nc = 0;
+    bool nvalid = locate(0, nr, nc);
+    GradTaps ntaps = {};
+    if (nvalid) ntaps = taps_at(nc, nr);   // the loads of batch b+1 are issued before batch b is evaluated
+    for (int base = 0; base < total; base += 64) {               // wave uniform
+        bool valid = nvalid;
+        const int r = nr, c = nc;
+        const GradTaps taps = ntaps;
+        nvalid = locate(base + 64, nr, nc);
+        if (nvalid) ntaps = taps_at(nc, nr);
+        int bin = 0;
+        float val = 0.0f;
+        if (valid) {
+            float gx = taps.xa - taps.xb, gy = taps.ya - taps.yb;
+            if (taps.bx) gx = 2.0f * gx;
+            if (taps.by) gy = 2.0f * gy;
+            const float gval = MAPS ? taps.xa : sqrtf(gx * gx + gy * gy);
+            float dif = (float)r - k.y;
+            float distsq = dif * dif;
+            dif = (float)c - k.z;
+            distsq = distsq + dif * dif;
+            valid = (gval > 0.0f) && (distsq < lim);
+            if (valid) {
+                const float earg = fast_div ? siftmath::div_by_reciprocal(-distsq, two_s2, r_two_s2) : -distsq / two_s2;
+                bool ok_a = true, ok_e;
+                float a = MAPS ? taps.xb : siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
+                float ew = siftmath::expf_fast_try(earg, ok_e);
+                if (!(ok_a && ok_e)) {
+                    if (!MAPS && !ok_a) a = siftmath::atan2f_(-gy, gx);
+                    if (!ok_e) ew = siftmath::expf_(earg);
+                }
+                bin = (int)siftmath::div_by_reciprocal(36.0f * (a + SM_PI_F + 0.001f), 2.0f * SM_PI_F, 1.0f / (2.0f * SM_PI_F));
+                valid = (bin >= 0) && (bin <= 36);
+                bin = min(max(bin, 0), 35);
+                val = ew * gval;
+            }
+            if (valid) atomicOr(reinterpret_cast<unsigned *>(L.mask) + 2 * bin + (lane >> 5), 1u << (lane & 31));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // owners: vote counts -> aligned pool segments
+        const uint2 mine = (lane < 36) ? L.mask[lane] : make_uint2(0u, 0u);
+        const int votes = __popc(mine.x) + __popc(mine.y);
+        const int padded = (votes + 3) & ~3;
+        const int seg = wave_prefix_incl(padded) - padded;
+        if (lane < 36) L.mbase[lane] = (unsigned)seg;
+        if (votes) reinterpret_cast<float4 *>(L.pool)[(seg + padded - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_wave_barrier();
+        // voters: value to segment base + rank among the voters of the same bin
+        {
+            const uint2 mk = L.mask[bin];
+            const unsigned mb = L.mbase[bin];
+            const int pos = mb + __builtin_amdgcn_mbcnt_hi(mk.y, __builtin_amdgcn_mbcnt_lo(mk.x, 0u));
+            if (valid) L.pool[pos] = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // owners: ordered sum of the segment
+        for (int k0 = 0; k0 < padded; k0 += 4) {
+            const float4 v = pool4[(seg + k0) >> 2];
+            h = h + v.x; h = h + v.y; h = h + v.z; h = h + v.w;
+        }
+        if (votes) L.mask[lane] = make_uint2(0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // six passes of circular [1 1 1]/3 smoothing, the maximum, further peaks: as in orientation_kernel
+    const int lp = (lane == 0) ? 35 : lane - 1, ln = (lane >= 35) ? 0 : lane + 1;
+    auto third = [&](float s) {
+        return (__builtin_fabsf(s) >= 1e-25f && __builtin_fabsf(s) <= 1e30f) ? siftmath::div_by_reciprocal(s, 3.0f, 1.0f / 3.0f)
+                                                                        : (float)((double)s / 3.0);
+    };
+#pragma unroll 1
+    for (int pass = 0; pass < 6; pass++) {
+        const float prev = __shfl(h, lp), nxt = __shfl(h, ln);
+        float nh = third((prev + h) + nxt);
+        const float nh0 = __shfl(nh, 0);
+        if (lane == 35) nh = third((prev + h) + nh0);
+        h = (lane < 36) ? nh : 0.0f;
+    }
+    float mx = (lane < 36) ? h : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float maxval = fmaxf(mx, 0.0f);
+    const uint64_t eq = __ballot(lane < 36 && h == maxval);
+    const int argmax = (maxval > 0.0f && eq) ? (__ffsll((unsigned long long)eq) - 1) : 0;
+    const float hp = __shfl(h, argmax == 0 ? 35 : argmax - 1);
+    const float hn = __shfl(h, argmax == 35 ? 0 : argmax + 1);
+    const float interp = 0.5f * (hp - hn) / (hp - 2.0f * maxval + hn);
+    const float angle = 2.0f * SM_PI_F * ((float)argmax + 0.5f + interp) / 36.0f - SM_PI_F;
+    const float hpp = __shfl(h, lp), hnn = __shfl(h, ln);
+    bool extra = (lane < 36) && h > hpp && h > hnn && h >= 0.8f * maxval && lane != argmax;
+    float a2 = 0.0f;
+    if (extra) {
+        const float it = 0.5f * (hpp - hnn) / (hpp - 2.0f * h + hnn);
+        a2 = (float)((double)(2.0f * SM_PI_F * ((float)lane + 0.5f + it)) / 36.0 - (double)SM_PI_F);
+        extra = (a2 >= -SM_PI_F) && (a2 <= SM_PI_F);
+    }
+    const uint64_t emask = __ballot(extra);
+    ox = k.z * (float)octsize; oy = k.y * (float)octsize; os = k.w * (float)octsize;
+    const float sum4 = ((ox + oy) + os) + angle;
+    const int nmain = (sum4 == sum4) ? 1 : 0;     // host NaN sieve of plan.py:545-550, done here
+    if (lane == 0 && nmain) peaks[0] = angle;
+    if (extra) peaks[nmain + __popcll((unsigned long long)(emask & ((1ull << lane) - 1ull)))] = a2;
+    __builtin_amdgcn_wave_barrier();
+    return nmain + __popcll((unsigned long long)emask);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Descriptor, streaming form: ONE WAVEFRONT per oriented keypoint, no workgroup barriers (keypoints_cpu.cl:36-161).

@@ -152,6 +152,12 @@ struct Options {
     int ori_small_blocks = 608;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints (512 until the descriptor launch was ordered: 0.809 ms; 576-640: 0.799-0.801; 704: 0.813)
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
+    int fused_kp = 0;        // development builds: orientation + description of a refined keypoint by one wave in ONE launch per group
+                             // (keypoint_fused_kernel), each group with its own refined list.  Bit-identical record sets; measured SLOWER:
+                             // headline 0.800 -> 0.952 ms, 2048^2 0.505 -> 0.627, 154 k keypoints 4.25 -> 4.76 -- the per-keypoint launches
+                             // are latency chains per wave (descriptor launch alone: 144 / 288 / 576 / 960 workgroups 775 / 438 / 288 / 242 us),
+                             // and the orientation of a keypoint (~13 us) lengthens the chain of the wave that then describes it (~69 us)
+                             // instead of running beside other keypoints' descriptors
     int glds = 0;            // development builds: LDS-DMA staging in the team blur of large planes (blur_glds_kernel; measured 3-5 % slower)
     int tail_fault = 0;      // diagnostic: the next `tail_fault` images that go through octave_tail_kernel are treated as if a
                              // workgroup of it had timed out (exercises the host's re-run path; results do not change)
@@ -208,6 +214,15 @@ struct siftmi_plan {
     size_t planes_floats = 0;
     bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves
     int later_group = 1;                      // group index of the later octaves in that image
+    bool fused = false;                       // that image: one fused orientation + description launch per group, one refined list per group
+    // refined list (entries, detection scale | octave << 8, counter) the refinement of octave `oct` appends to
+    // (group 0 = octave 0 unless the tail kernel takes every octave; the later group's list lives in the oriented list's
+    // arrays, which a fused image does not use)
+    int tail_first_cur = 0;                   // first octave of that image's tail launch (n_oct: none)
+    int group_of(int oct) const { return (oct == 0 && tail_first_cur != 0) ? 0 : 1; }
+    float4 *kp_of(int oct) const { return (fused && group_of(oct)) ? okp : kp; }
+    int *kp_aux_of(int oct) const { return (fused && group_of(oct)) ? oaux : kp_scale; }
+    int *kp_counter_of(int oct) const { return fused ? &cnt->kp_count[group_of(oct)] : &cnt->n_kp; }
     hipEvent_t ev_maps0 = nullptr;
     bool maps_unavailable = false;   // the lazy allocation of the gradient maps failed once: dense frames keep the lazy forms
     hipEvent_t ev_join = nullptr;
@@ -533,7 +548,7 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int band = -1
         }
         const int blocks = std::max(1, (nx * ny + 3) / 4);
         const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
-        const RefineArgs ra = {p->par.peak_thresh, (float)p->par.init_sigma, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, oct};
+        const RefineArgs ra = {p->par.peak_thresh, (float)p->par.init_sigma, p->kp_of(oct), p->kp_aux_of(oct), p->kp_counter_of(oct), kcap, oct};
         // One launch detects and refines (the survivors of the edge test are refined by the wave that parked them: no
         // candidate list, no second launch) unless every stage is bracketed on its own (full profile) or option
         // "fused_refine" says otherwise (0: never, 1: planes below 1400^2, 2: every plane).
@@ -554,8 +569,8 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int band = -1
         snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)p->cand,
-                           (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp,
-                           p->kp_scale, &p->cnt->n_kp, kcap, oct, &p->cnt->overflow,
+                           (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp_of(oct),
+                           p->kp_aux_of(oct), p->kp_counter_of(oct), kcap, oct, &p->cnt->overflow,
                            band >= 0 ? (const int *)&p->cnt->grp_cand_start[band] : (const int *)nullptr);
     }
     if (band >= 0) hipLaunchKernelGGL(mark_kp_kernel, dim3(1), dim3(1), 0, st, p->cnt, band, kcap, oct, kcap);
@@ -613,7 +628,7 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
     const int kcap = (int)p->kpsize;
     hipLaunchKernelGGL(octave_tail_kernel, dim3((unsigned)a.n), dim3(SIFT_TAIL_THREADS), lds, st, a, p->par.border_dist,
                        contrast_threshold(p->par), p->par.peak_thresh, (float)p->par.init_sigma, p->tail_cand, p->tail_cand_cap,
-                       p->cnt->n_cand, p->cnt->tail_ready, p->kp, p->kp_scale, &p->cnt->n_kp, kcap, &p->cnt->overflow, &p->cnt->tail_timeout);
+                       p->cnt->n_cand, p->cnt->tail_ready, p->kp_of(first), p->kp_aux_of(first), p->kp_counter_of(first), kcap, &p->cnt->overflow, &p->cnt->tail_timeout);
     return SIFTMI_OK;
 }
 
@@ -694,9 +709,36 @@ void launch_gradient_maps(siftmi_plan *p, int oct_lo, int oct_hi, hipStream_t st
     hipLaunchKernelGGL(gradient_maps_kernel, dim3(blocks), dim3(256), 0, st, tab, oct_lo, oct_hi, total, p->gmap, p->omap);
 }
 
+// Fused form (option "fused_kp"): ONE launch orients and describes every refined keypoint of the group's own list
+// (k_descriptor.hpp: keypoint_fused_kernel).  No orientation launch, no mark_group_kernel, no event between the groups.
+void launch_fused_group(siftmi_plan *p, int group, hipStream_t st) {
+    const int kcap = (int)p->kpsize;
+    const OctaveTable tab = octave_table(p);
+    char lab[96];
+    snprintf(lab, sizeof lab, "orientation_assignment + descriptors group %d", group);
+    Scope sc(p, lab, false, 0, st);
+    const int desc_blocks = p->opt.desc_blocks;
+    const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
+    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
+    const bool maps = group == 0 ? p->maps_g0 : p->maps_g1;
+    const float4 *kp = group ? p->okp : p->kp;
+    const int *aux = group ? p->oaux : p->kp_scale;
+#ifdef SIFT_DEV_VARIANTS
+    if (maps)
+        hipLaunchKernelGGL(keypoint_fused_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab, p->par.ori_sigma, kp, aux,
+                           p->cnt, group, kcap, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_dynamic, desc_blocks, small_blocks);
+    else
+        hipLaunchKernelGGL(keypoint_fused_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab, p->par.ori_sigma, kp, aux,
+                           p->cnt, group, kcap, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
+#else
+    (void)kcap; (void)tab; (void)desc_pad; (void)small_blocks; (void)maps; (void)kp; (void)aux;
+#endif
+}
+
 // orientation + descriptor for every refined keypoint of one group of octaves, on one stream; `mark_event`: recorded once
 // the group's ranges are frozen (the next group may start appending)
 void launch_describe_group(siftmi_plan *p, int group, hipStream_t st, hipEvent_t mark_event = nullptr) {
+    if (p->fused) { launch_fused_group(p, group ? 1 : 0, st); return; }
     launch_orient_group(p, group, st, false);
     if (mark_event) hipEventRecord(mark_event, st);
     launch_descriptor_group(p, group, st);
@@ -914,6 +956,9 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_dynamic") o.desc_dynamic = v != 0;
     else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
     else if (n == "fused_shrink") o.fused_shrink = v != 0;
+#ifdef SIFT_DEV_VARIANTS
+    else if (n == "fused_kp") o.fused_kp = v != 0;
+#endif
     else if (n == "fused_refine") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fused_refine must be 0, 1 or 2"); o.fused_refine = (int)v; }
     else if (n == "maps") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "maps must be 0 (never), 1 (always) or 2 (by the previous image)"); o.maps = v; }
     else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
@@ -1074,6 +1119,10 @@ int enqueue_body(siftmi_plan *p) {
 #endif
     p->bands_last = nbands;
     const int later = nbands ? nbands : 1;         // group index of the later octaves
+    // fused per-keypoint launches: not with a stage-by-stage profile (every stage keeps its launch and label), not banded,
+    // not with windows beyond the row tables
+    p->tail_first_cur = tail_first;
+    p->fused = p->opt.fused_kp && p->profile <= 1 && !nbands && p->desc_rows && !p->opt.desc_stream;
     // Gradient maps for the per-keypoint kernels of this image (option "maps"): large frames, by the previous image's counts
     {
         const int mode = p->opt.maps;
@@ -1179,7 +1228,7 @@ int enqueue_body(siftmi_plan *p) {
                     HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
                     HIPCHK(hipStreamWaitEvent(ts, p->ev_pyr[(size_t)oct], 0));
                 }
-                if (oct == 1 || split) HIPCHK(hipStreamWaitEvent(ts, p->ev_mark0, 0));
+                if (!p->fused && (oct == 1 || split)) HIPCHK(hipStreamWaitEvent(ts, p->ev_mark0, 0));
             }
             int rc = launch_tail(p, oct, ts);
             if (rc) return rc;
@@ -1206,7 +1255,7 @@ int enqueue_body(siftmi_plan *p) {
         // ev_pyr[0]).  Off by default: the host is not what delays that chain.
         if (oct == 0 && chain0 && p->opt.early_pyr && p->n_oct > 1 && tail_first != 1 && (rc = build_pyramid(1))) return rc;
         if (two) {
-            if (oct == 1) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
+            if (oct == 1 && !p->fused) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
             if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, (oct == 0 && pyr0_done) ? pyr0_done : p->ev_pyr[(size_t)oct], 0));
         }
 #ifdef SIFT_DEV_VARIANTS
@@ -1313,7 +1362,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         }
     }
     p->last_count = n;
-    p->last_group0 = hc.grp_out_end[p->bands_last ? p->bands_last - 1 : 0] - hc.grp_out_start[0];
+    p->last_group0 = p->fused ? p->hb->c.grp_made[0] : hc.grp_out_end[p->bands_last ? p->bands_last - 1 : 0] - hc.grp_out_start[0];
     p->last_group1 = (int)n - p->last_group0;
     *n_out = n;
     if (overflow) *overflow = ovf;

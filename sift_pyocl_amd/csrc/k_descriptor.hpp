@@ -46,6 +46,12 @@
 namespace siftk {
 
 #define SIFT_DESC_MAXRAD 127
+#ifndef SIFT_DESC_PIPE
+#define SIFT_DESC_PIPE 0       // 1: software-pipelined batch loop of the wave-per-keypoint form (desc_one_wave; needs SIFT_DESC_WAVES 3).
+                               // Bit-identical; measured no faster (round 4, interleaved A/B of the two builds): group 0 of the headline
+                               // frame alone 0.279 against 0.282-0.298 ms, 154 k keypoints 2.68 against 2.49 ms (three waves per SIMD
+                               // instead of four), whole headline call 0.818 against 0.796 ms -- see the loop's comment
+#endif
 #ifndef SIFT_DESC_WAVES
 #define SIFT_DESC_WAVES 4      // 128 VGPRs, no scratch: 4.03 ms against 4.44 ms at 5 waves (96 VGPRs, 76 B of scratch) on 154 k keypoints
 #endif
@@ -63,8 +69,9 @@ struct alignas(16) DescPool {
 };
 struct alignas(16) DescRowLds {
     DescPool P;                                // P.pool doubles as the 128 squares of the normalisation (step 4)
-    int row_start[2 * SIFT_DESC_MAXRAD + 4];   // exclusive prefix of the per-row run lengths; [S] = total
-    short row_jlo[2 * SIFT_DESC_MAXRAD + 4];   // first in-window jj of every row
+    // per window row: (exclusive prefix of the per-row run lengths) << 8 | (first in-window jj + 128); rows [S, S + 4): ~0
+    // (the look-up reads four rows ahead; a row start beyond every rank never counts as passed)
+    unsigned row_pack[2 * SIFT_DESC_MAXRAD + 8];
 };
 
 __device__ __forceinline__ unsigned desc_lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // LDS byte address of a __shared__ object
@@ -229,14 +236,20 @@ __device__ __forceinline__ void desc_fetch(const DescWindow &w, int ii, int jj, 
     }
 }
 
-// One sample of the descriptor window: everything keypoints_cpu.cl:74-117 does for it, except the additions.
-// tgs[c] (+ the cell's constant): LDS address of the S word of cell c; tgt[n] (+ the cell's constant): LDS address of
-// the entry of the bin contribution n goes to, cval[n] its value; the dummies where the cell does not exist or the lane
-// is not `live`.
+// One sample of the descriptor window: everything keypoints_cpu.cl:74-117 does for it, except the additions -- in four
+// parts, so that the software-pipelined batch loop (desc_one_wave) can put one of them behind each of the LDS round trips
+// of the PREVIOUS batch's routing; desc_eval below runs them back to back.
+//   1. window coordinates, gradient, argument of the weight        2. orientation (Ziv candidate)
+//   3. Gaussian weight (Ziv candidate) + the rare fall-backs        4. bins, the eight values, routing addresses
 // INTERIOR: the whole window lies at least one pixel inside the plane (no one-sided differences, image.cl:58-77).
+struct DescEvalState {
+    desc_f2 RC;               // (rx, cx)
+    float gx, gy, g, earg, o, ew;
+    bool ok_a, ok_e;
+    siftmath::Atan2Try at;    // the orientation's candidate between parts 2 and 3
+};
 template <bool INTERIOR, bool MAPS>
-__device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample &q, bool live, const double *fold, const DescRoute &rt,
-                                          unsigned (&tgs)[4], unsigned (&tgt)[8], float (&cval)[8]) {
+__device__ __forceinline__ void desc_eval1(const DescWindow &w, const DescSample &q, DescEvalState &st) {
     // ---- window coordinates (keypoints_cpu.cl:64-67): rx = ((cos*i - sin*j) - drow) / spacing + 1.5, cx likewise.
     //      Both at once in packed-f32 instructions: -(cos*j) == (-cos)*j exactly, so uc = sin*i - (-cos)*j.
     const int ii = q.ii, jj = q.jj;
@@ -255,9 +268,7 @@ __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample 
     } else {
         Q = (desc_f2){U.x / w.spacing, U.y / w.spacing};
     }
-    const desc_f2 RC = Q + (desc_f2){1.5f, 1.5f};
-    const float rx = RC.x, cx = RC.y;
-
+    st.RC = Q + (desc_f2){1.5f, 1.5f};
     // ---- gradient of blur[scale] at the sample (image.cl:58-77)
     float gx = q.right - q.left, gy = q.up - q.down;
     if (!INTERIOR) {
@@ -265,20 +276,36 @@ __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample 
         if ((x == 0) || (x == w.W - 1)) gx = 2.0f * gx;
         if ((y == 0) || (y == w.H - 1)) gy = 2.0f * gy;
     }
-    const float g = MAPS ? q.right : sqrtf(gx * gx + gy * gy);
-    const desc_f2 E = RC - (desc_f2){1.5f, 1.5f};
+    st.gx = gx; st.gy = gy;
+    st.g = MAPS ? q.right : sqrtf(gx * gx + gy * gy);
+    st.o = MAPS ? q.left : 0.0f;
+    const desc_f2 E = st.RC - (desc_f2){1.5f, 1.5f};
     const desc_f2 E2 = E * E;
-    const float earg = -0.125f * (E2.x + E2.y);
-    // the two Ziv candidates in one basic block (two independent binary64 chains side by side), one branch for both
-    bool ok_a = true, ok_e;
-    float o = MAPS ? q.left : siftmath::atan2f_fast_try(-gy, gx, fold, ok_a);
-    float ew = siftmath::expf_fast_try(earg, ok_e);
-    if (!(ok_a && ok_e)) {                        // 2^-14 of the samples: the defining functions
-        if (!MAPS && !ok_a) o = siftmath::atan2f_(-gy, gx);
-        if (!ok_e) ew = siftmath::expf_(earg);
+    st.earg = -0.125f * (E2.x + E2.y);
+    st.ok_a = true;
+}
+template <bool MAPS>
+__device__ __forceinline__ void desc_eval2(DescEvalState &st, const double *fold) {
+    if (!MAPS) siftmath::atan2f_fast_begin(-st.gy, st.gx, fold, st.at);      // (its table value is on its way while part 3 starts)
+}
+template <bool MAPS>
+__device__ __forceinline__ void desc_eval3(DescEvalState &st) {
+    st.ew = siftmath::expf_fast_try(st.earg, st.ok_e);
+    if (!MAPS) st.o = siftmath::atan2f_fast_end(st.at, st.ok_a);
+    if (!(st.ok_a && st.ok_e)) {                  // 2^-14 of the samples: the defining functions
+        if (!MAPS && !st.ok_a) st.o = siftmath::atan2f_(-st.gy, st.gx);
+        if (!st.ok_e) st.ew = siftmath::expf_(st.earg);
     }
-    const float mag = g * ew;
-    o = o - w.angle;
+}
+// tgs[c] (+ the cell's constant): LDS address of the S word of cell c; tgt[n] (+ the cell's constant): LDS address of
+// the entry of the bin contribution n goes to, cval[n] its value; the dummies where the cell does not exist or the lane
+// is not `live`.
+__device__ __forceinline__ void desc_eval4(const DescWindow &w, const DescEvalState &st, bool live, const DescRoute &rt,
+                                           unsigned (&tgs)[4], unsigned (&tgt)[8], float (&cval)[8]) {
+    const desc_f2 RC = st.RC;
+    const float rx = RC.x, cx = RC.y;
+    const float mag = st.g * st.ew;
+    float o = st.o - w.angle;
     // keypoints_cpu.cl:85-87: while (o > 2 pi) o -= 2 pi; while (o < 0) o += 2 pi.  o and angle lie in [-pi, pi]: the first
     // loop never runs and the second at most once -- one select; the loops themselves only where a lane is still out of
     // range after it (wave uniform test; same result: a lane that was negative has had its first addition, the
@@ -322,6 +349,17 @@ __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample 
     tgt[2] = v1 ? t0 : rt.dummy - 16u * SIFT_DESC_C1;   tgt[3] = v1 ? t1 : rt.dummy - 16u * SIFT_DESC_C1;
     tgt[4] = v2 ? t0 : rt.dummy - 16u * SIFT_DESC_C2;   tgt[5] = v2 ? t1 : rt.dummy - 16u * SIFT_DESC_C2;
     tgt[6] = v3 ? t0 : rt.dummy - 16u * SIFT_DESC_C3;   tgt[7] = v3 ? t1 : rt.dummy - 16u * SIFT_DESC_C3;
+}
+// the four parts back to back (workgroup-per-keypoint form; the two Ziv candidates share a basic block: two independent
+// binary64 chains side by side, one branch for both fall-backs)
+template <bool INTERIOR, bool MAPS>
+__device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample &q, bool live, const double *fold, const DescRoute &rt,
+                                          unsigned (&tgs)[4], unsigned (&tgt)[8], float (&cval)[8]) {
+    DescEvalState st;
+    desc_eval1<INTERIOR, MAPS>(w, q, st);
+    desc_eval2<MAPS>(st, fold);
+    desc_eval3<MAPS>(st);
+    desc_eval4(w, st, live, rt, tgs, tgt, cval);
 }
 
 // Steps 3a-3c for one batch of a wave.  On return the pool holds every bin's values in lane order; (base, padded counts)
@@ -517,23 +555,173 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
             int c = jhi - jlo + 1;
             if (r >= S || yy < 0 || yy >= H || c < 0) c = 0;
             const int incl = wave_prefix_incl(c);
-            if (r < S) { L.row_start[r] = carry + incl - c; L.row_jlo[r] = (short)jlo; }
+            // (an empty row may report a first jj of R + 1 = 128: clamped, it is never the row of a rank)
+            if (r < S) L.row_pack[r] = ((unsigned)(carry + incl - c) << 8) | (unsigned)(min(jlo, 127) + 128);
             carry += __builtin_amdgcn_readlane(incl, 63);
         }
-        if (lane == 0) L.row_start[S] = carry;
+        if (lane < 4) L.row_pack[S + lane] = ~0u;
         const int total = carry;
         __builtin_amdgcn_wave_barrier();
 
-        // ---- 2 + 3. 64 ranks at a time
+        // ---- 2 + 3. 64 ranks at a time.  Two forms of the loop (SIFT_DESC_PIPE); the product build uses the plain one.
+        //      SOFTWARE-PIPELINED form (built in round 4 on the hypothesis that the launch is bound by the LDS round trips of
+        //      a batch's routing -- contributor atomics -> masks -> entries -> pool slots -> sums --: alone it scales with the
+        //      number of resident waves, 288 / 576 / 960 workgroups 438 / 288 / 242 us).  Every LDS request of batch b's routing
+        //      is followed by a quarter of the EVALUATION of batch b + 1 (which touches no LDS but the 8-byte fold entry)
+        //      before its result is used (checked in the disassembly: no wait is left in front of a stage but the one for the
+        //      words that stage consumes, an evaluation part earlier):
+        //          R1  atomics of b, S words requested, row table of b + 2 requested       | E1  coordinates, gradient of b + 1
+        //          R2  masks, counts, prefix sum, entries published, entries requested,    | E2  orientation of b + 1
+        //              rows of b + 2 resolved, its four neighbours requested (HBM)         |
+        //          R3  ranks, pool stores, the owners' segments requested                  | E3  weight of b + 1 (+ rare fall-backs)
+        //          R4  ordered sums, S words cleared                                       | E4  bins, values, addresses of b + 1
+        //      LDS operations of one wave execute in program order, so the stages need no waits between them -- only the
+        //      compiler must not reorder: every stage boundary is a scheduling barrier.  The same additions in the same
+        //      order as the plain loop.  RESULT: no faster at the same number of waves, and it needs 152-168 VGPRs (three waves
+        //      per SIMD; at 128 it spills 29).  What the hypothesis missed: a wave issues one instruction per ~5 cycles
+        //      whatever it is (profiles/r04/valu_issue_rate.txt, one wave per SIMD), a batch is ~600 instructions (418 VALU,
+        //      62 SALU, 36 LDS, ~85 waits / nops / branches) = ~3000 cycles of the wave's own issue against ~700 of exposed
+        //      LDS latency, and the pipelined loop does not have fewer instructions.  More waves or fewer instructions move
+        //      this launch; overlap inside a wave does not.
         float acc0 = 0.0f, acc1 = 0.0f;  // bins lane and lane + 64
+#if SIFT_DESC_PIPE
+        int rcur = 0;                    // row of this lane's current rank (ranks only grow)
+        unsigned rword = L.row_pack[0];  // ... and its packed (start, first jj)
+        DescSample smp;                  // neighbours of the batch that is evaluated next
+        unsigned wd[4];
+        auto row_request = [&]() {
+            wd[0] = L.row_pack[rcur + 1]; wd[1] = L.row_pack[rcur + 2]; wd[2] = L.row_pack[rcur + 3]; wd[3] = L.row_pack[rcur + 4];
+        };
+        // the row of rank s0 + lane among the current one and the four requested (a lane whose rank lies further on -- the
+        // short rows at a window corner -- looks again: wave uniform, rare), then the four neighbours of that sample.
+        // A lane beyond the last rank takes the last sample again, aimed at its dummy entry: no divergence, no defaults.
+        auto row_resolve_fetch = [&](int s0) {
+            const int sc = min(s0 + lane, total - 1);
+            const unsigned lim = (unsigned)(sc + 1) << 8;
+            bool more = true;
+            for (;;) {
+                const bool a0 = wd[0] < lim, a1 = wd[1] < lim, a2 = wd[2] < lim, a3 = wd[3] < lim;
+                if (more) {
+                    rword = a3 ? wd[3] : (a2 ? wd[2] : (a1 ? wd[1] : (a0 ? wd[0] : rword)));
+                    rcur += (int)a0 + (int)a1 + (int)a2 + (int)a3;
+                }
+                more = more && a3;
+                if (!__ballot(more)) break;
+                row_request();
+            }
+            const int ii = rcur - R, jj = (int)(rword & 0xffu) - 128 + (sc - (int)(rword >> 8));
+            if (w.interior) desc_fetch<true, MAPS>(w, ii, jj, smp);
+            else desc_fetch<false, MAPS>(w, ii, jj, smp);
+        };
+        unsigned tgs[4], tgt[8];
+        float cval[8];
+        DescEvalState st;
+        if (total > 0) {
+            // prologue: batch 0 evaluated, batch 1's neighbours requested
+            row_request(); row_resolve_fetch(0);
+            if (w.interior) desc_eval1<true, MAPS>(w, smp, st); else desc_eval1<false, MAPS>(w, smp, st);
+            desc_eval2<MAPS>(st, fold);
+            desc_eval3<MAPS>(st);
+            desc_eval4(w, st, lane < total, rt, tgs, tgt, cval);
+            row_request(); row_resolve_fetch(64);
+        }
+        const unsigned pool0 = desc_lds_addr(&L.P.pool[0]);
+        const int prev = (lane & ~7) | ((lane + 7) & 7);           // same cell, orientation bin - 1 (bins lane and lane + 64 alike)
+        for (int s0 = 0; s0 < total; s0 += 64) {
+            const bool have_next = s0 + 64 < total;                // wave uniform
+            // ---- R1
+            desc_or32<4 * SIFT_DESC_C0>(tgs[0], rt.bit); desc_or32<4 * SIFT_DESC_C1>(tgs[1], rt.bit);
+            desc_or32<4 * SIFT_DESC_C2>(tgs[2], rt.bit); desc_or32<4 * SIFT_DESC_C3>(tgs[3], rt.bit);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned s_al = L.P.S[0][lane], s_alp = L.P.S[0][prev], s_ah = L.P.S[1][lane], s_ahp = L.P.S[1][prev];
+            const unsigned s_bl = L.P.S[0][lane + 64], s_blp = L.P.S[0][prev + 64], s_bh = L.P.S[1][lane + 64], s_bhp = L.P.S[1][prev + 64];
+            if (s0 + 128 < total) row_request();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- E1
+            if (have_next) { if (w.interior) desc_eval1<true, MAPS>(w, smp, st); else desc_eval1<false, MAPS>(w, smp, st); }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- R2: bin owners: mask = S[ob] | S[ob - 1] of the cell, counts, 16-byte aligned pool segments from a wave prefix sum
+            const unsigned alo = s_al | s_alp, ahi = s_ah | s_ahp, blo = s_bl | s_blp, bhi = s_bh | s_bhp;
+            const int cnta = __popc(alo) + __popc(ahi), cntb = __popc(blo) + __popc(bhi);
+            const int pa = (cnta + 3) & ~3, pb = (cntb + 3) & ~3;
+            const int base_a = wave_prefix_incl(pa + pb) - (pa + pb);
+            const int base_b = base_a + pa;
+            *reinterpret_cast<uint4 *>(&L.P.ent[lane]) = make_uint4(alo, ahi, pool0 + 4u * (unsigned)base_a, 0u);
+            *reinterpret_cast<uint4 *>(&L.P.ent[lane + 64]) = make_uint4(blo, bhi, pool0 + 4u * (unsigned)base_b, 0u);
+            // the last group of four of every segment starts as +0: its padding then adds +0 (an exact no-op on these
+            // non-negative sums), so the owners' loops need no per-element masks
+            if (cnta) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)base_b) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
+            if (cntb) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)(base_b + pb)) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_wave_barrier();
+            if (s0 + 128 < total) row_resolve_fetch(s0 + 128);    // (after E1: `smp` is free again; before the entry reads: its row words arrived with the S words)
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4 e0 = desc_entry<16 * SIFT_DESC_C0>(tgt[0]), e1 = desc_entry<16 * SIFT_DESC_C0>(tgt[1]);
+            const uint4 e2 = desc_entry<16 * SIFT_DESC_C1>(tgt[2]), e3 = desc_entry<16 * SIFT_DESC_C1>(tgt[3]);
+            const uint4 e4 = desc_entry<16 * SIFT_DESC_C2>(tgt[4]), e5 = desc_entry<16 * SIFT_DESC_C2>(tgt[5]);
+            const uint4 e6 = desc_entry<16 * SIFT_DESC_C3>(tgt[6]), e7 = desc_entry<16 * SIFT_DESC_C3>(tgt[7]);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- E2
+            if (have_next) desc_eval2<MAPS>(st, fold);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- R3: every value to segment start + 4 * rank among the contributors of its bin (mbcnt: set bits of the mask
+            //          below this lane); then the owners' first two groups of four
+            // (the count starts from the entry's fourth word, a zero: with every word of the 16-byte read in use the register
+            // allocator cannot hand a word of an entry still in flight to the evaluation stage -- a write to it would wait
+            // for the read, i.e. put the round trip back on the wave's path)
+            auto place = [&](const uint4 &en, float v) {
+                *reinterpret_cast<desc_lds_f32 *>(en.z + 4u * __builtin_amdgcn_mbcnt_hi(en.y, __builtin_amdgcn_mbcnt_lo(en.x, en.w))) = v;
+            };
+            place(e0, cval[0]); place(e1, cval[1]); place(e2, cval[2]); place(e3, cval[3]);
+            place(e4, cval[4]); place(e5, cval[5]); place(e6, cval[6]); place(e7, cval[7]);
+            __builtin_amdgcn_wave_barrier();
+            const int qa = base_a >> 2, ea = pa >> 2, eb = pb >> 2, qb = qa + ea;
+            const float4 a0 = pool4[ea > 0 ? qa : 224], a1 = pool4[ea > 1 ? qa + 1 : 224];
+            const float4 b0 = pool4[eb > 0 ? qb : 224], b1 = pool4[eb > 1 ? qb + 1 : 224];
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- E3
+            if (have_next) desc_eval3<MAPS>(st);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- R4: ordered sums of this lane's two bins (desc_sum_pair, its first reads issued above)
+            acc0 = desc_add(acc0, a0.x); acc1 = desc_add(acc1, b0.x);
+            acc0 = desc_add(acc0, a0.y); acc1 = desc_add(acc1, b0.y);
+            acc0 = desc_add(acc0, a0.z); acc1 = desc_add(acc1, b0.z);
+            acc0 = desc_add(acc0, a0.w); acc1 = desc_add(acc1, b0.w);
+            acc0 = desc_add(acc0, a1.x); acc1 = desc_add(acc1, b1.x);
+            acc0 = desc_add(acc0, a1.y); acc1 = desc_add(acc1, b1.y);
+            acc0 = desc_add(acc0, a1.z); acc1 = desc_add(acc1, b1.z);
+            acc0 = desc_add(acc0, a1.w); acc1 = desc_add(acc1, b1.w);
+            if (__ballot(ea > 2 || eb > 2)) {                 // wave uniform
+                const int nmax = max(ea, eb);
+                float4 va = pool4[ea > 2 ? qa + 2 : 224], vb = pool4[eb > 2 ? qb + 2 : 224];
+                for (int g4 = 2; g4 < nmax; g4++) {
+                    const float4 ca = va, cb = vb;
+                    va = pool4[(g4 + 1 < ea) ? qa + g4 + 1 : 224];
+                    vb = pool4[(g4 + 1 < eb) ? qb + g4 + 1 : 224];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = desc_add(acc0, ca.x); acc1 = desc_add(acc1, cb.x);
+                    acc0 = desc_add(acc0, ca.y); acc1 = desc_add(acc1, cb.y);
+                    acc0 = desc_add(acc0, ca.z); acc1 = desc_add(acc1, cb.z);
+                    acc0 = desc_add(acc0, ca.w); acc1 = desc_add(acc1, cb.w);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            desc_route_reset(L.P, lane);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- E4
+            if (have_next) desc_eval4(w, st, s0 + 64 + lane < total, rt, tgs, tgt, cval);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         int rcur = 0;                    // row of this lane's current rank (ranks only grow)
         DescSample nxt;
         // a lane beyond the last rank evaluates the last sample again, aimed at its dummy entry: no divergence, no
         // default values to materialise
         auto fetch = [&](int s0) {
             const int sc = min(s0 + lane, total - 1);
-            while (sc >= L.row_start[rcur + 1]) rcur++;
-            const int ii = rcur - R, jj = (int)L.row_jlo[rcur] + (sc - L.row_start[rcur]);
+            while (sc >= (int)(L.row_pack[rcur + 1] >> 8)) rcur++;
+            const unsigned rw = L.row_pack[rcur];
+            const int ii = rcur - R, jj = (int)(rw & 0xffu) - 128 + (sc - (int)(rw >> 8));
             if (w.interior) desc_fetch<true, MAPS>(w, ii, jj, nxt);
             else desc_fetch<false, MAPS>(w, ii, jj, nxt);
         };
@@ -553,6 +741,7 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
             desc_route_reset(L.P, lane);
             __builtin_amdgcn_wave_barrier();
         }
+#endif
 
         // ---- 4. normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160): the reference sums the 128
         //         squares sequentially in index order; every lane repeats that sum from LDS (eight 16-byte reads in

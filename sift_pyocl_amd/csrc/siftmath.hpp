@@ -240,14 +240,21 @@ __device__ __forceinline__ float expf_fast(float xf) {
 // |num/den - k/8| <= 1/16 + 2^-20 serves), t = (num - c den) / (den + c num) by a Newton reciprocal (two steps from the
 // hardware seed: error < 2^-50), odd Taylor polynomial through t^11 (|t| <= 0.0626: truncation < 2^-51 relative), and
 // the three reflections of atan2f_ folded into one table value (c_atan_fold).  `fold` is the block's LDS copy.
-__device__ __forceinline__ float atan2f_fast_try(float yf, float xf, const double *fold, bool &ok) {
+// (in two halves: the table value is requested from LDS by the first and used by the second, so that a caller can put
+// other work between them -- the descriptor kernel's pipelined batch loop does)
+struct Atan2Try { double at, base; bool in_range, sub, neg; };
+__device__ __forceinline__ void atan2f_fast_begin(float yf, float xf, const double *fold, Atan2Try &T) {
     const float ay = __builtin_fabsf(yf), ax = __builtin_fabsf(xf);
     const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
     // guarded range: no zero / huge / NaN operand (fmin / fmax drop a NaN), no sub-normal result
-    const bool in_range = ax <= 1e18f && ay <= 1e18f && mn >= 1e-18f;
+    T.in_range = ax <= 1e18f && ay <= 1e18f && mn >= 1e-18f;
     const bool swap = ay > ax;
     int k = (int)(mn * __builtin_amdgcn_rcpf(mx) * 8.0f + 0.5f);               // 0..8 inside the guarded range
     k = k < 0 ? 0 : (k > 8 ? 8 : k);                                           // (keeps the table index in bounds outside it)
+    const int f = (swap ? 1 : 0) + (__builtin_signbitf(xf) ? 2 : 0);
+    T.base = fold[f * 9 + k];
+    T.sub = (f == 1 || f == 2);
+    T.neg = __builtin_signbitf(yf);
     const double c = (double)((float)k * 0.125f);
     const double num = (double)mn, den = (double)mx;
     const double tn = __builtin_fma(-c, den, num), td = __builtin_fma(c, num, den);
@@ -261,13 +268,18 @@ __device__ __forceinline__ float atan2f_fast_try(float yf, float xf, const doubl
     p = fma3(p, t2, -0x1.2492492492492p-3);
     p = fma3(p, t2, 0x1.999999999999ap-3);
     p = fma3(p, t2, -0x1.5555555555555p-2);
-    const double at = __builtin_fma(t * t2, p, t);               // atan(t), same sign as t
-    const int f = (swap ? 1 : 0) + (__builtin_signbitf(xf) ? 2 : 0);
-    const double base = fold[f * 9 + k];
-    const double res = (f == 1 || f == 2) ? base - at : base + at;
-    ok = in_range && f32_rounding_is_safe(res);
+    T.at = __builtin_fma(t * t2, p, t);               // atan(t), same sign as t
+}
+__device__ __forceinline__ float atan2f_fast_end(const Atan2Try &T, bool &ok) {
+    const double res = T.sub ? T.base - T.at : T.base + T.at;
+    ok = T.in_range && f32_rounding_is_safe(res);
     const float out = (float)res;
-    return __builtin_signbitf(yf) ? -out : out;
+    return T.neg ? -out : out;
+}
+__device__ __forceinline__ float atan2f_fast_try(float yf, float xf, const double *fold, bool &ok) {
+    Atan2Try T;
+    atan2f_fast_begin(yf, xf, fold, T);
+    return atan2f_fast_end(T, ok);
 }
 __device__ __forceinline__ float atan2f_fast(float yf, float xf, const double *fold) {
     bool ok;

@@ -57,6 +57,17 @@ namespace siftk {
 #endif
 
 typedef float desc_f2 __attribute__((ext_vector_type(2)));
+#ifdef SIFT_PHASE_CLOCK
+#define PH_PARAM , PhaseClock *php
+#define PH_PASS , &ph
+#define PH_NONE , nullptr
+#define PHP_MARK(k) do { if (php) php->mark((k), lane); } while (0)
+#else
+#define PH_PARAM
+#define PH_PASS
+#define PH_NONE
+#define PHP_MARK(k)
+#endif
 
 struct alignas(16) DescEntry { unsigned mlo, mhi, seg, spare; };     // contributor mask (lanes 0-31 / 32-63), LDS byte address of the first contributor's pool slot
 #define SIFT_DESC_DUMMY 128                    // entry [128]: the shared dummy {~0, ~0, dump slots}: a lane's rank in it is its lane number
@@ -72,6 +83,9 @@ struct alignas(16) DescRowLds {
     // per window row: (exclusive prefix of the per-row run lengths) << 8 | (first in-window jj + 128); rows [S, S + 4): ~0
     // (the look-up reads four rows ahead; a row start beyond every rank never counts as passed)
     unsigned row_pack[2 * SIFT_DESC_MAXRAD + 8];
+#ifdef SIFT_PHASE_CLOCK
+    unsigned long long ph[16];
+#endif
 };
 
 __device__ __forceinline__ unsigned desc_lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // LDS byte address of a __shared__ object
@@ -365,7 +379,7 @@ __device__ __forceinline__ void desc_eval(const DescWindow &w, const DescSample 
 // Steps 3a-3c for one batch of a wave.  On return the pool holds every bin's values in lane order; (base, padded counts)
 // of the caller's two bins come back for the owners' sums.
 __device__ __forceinline__ void desc_route(DescPool &P, const DescRoute &rt, const unsigned (&tgs)[4], const unsigned (&tgt)[8],
-                                           const float (&cval)[8], int lane, int &base_a, int &pa, int &pb) {
+                                           const float (&cval)[8], int lane, int &base_a, int &pa, int &pb PH_PARAM) {
     // ---- 3a. one 32-bit LDS atomic per cell
     desc_or32<4 * SIFT_DESC_C0>(tgs[0], rt.bit); desc_or32<4 * SIFT_DESC_C1>(tgs[1], rt.bit);
     desc_or32<4 * SIFT_DESC_C2>(tgs[2], rt.bit); desc_or32<4 * SIFT_DESC_C3>(tgs[3], rt.bit);
@@ -386,6 +400,7 @@ __device__ __forceinline__ void desc_route(DescPool &P, const DescRoute &rt, con
     if (cnta) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)base_b) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
     if (cntb) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)(base_b + pb)) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_wave_barrier();
+    PHP_MARK(6);
     // ---- 3c. every value to segment start + 4 * rank among the contributors of its bin (mbcnt: set bits of the mask
     //          below this lane); the eight 16-byte reads are in flight together
     // (two rounds of four: eight 12-byte entries at once cost 24 registers at the kernel's register peak)
@@ -404,6 +419,7 @@ __device__ __forceinline__ void desc_route(DescPool &P, const DescRoute &rt, con
         place(e4, cval[4]); place(e5, cval[5]); place(e6, cval[6]); place(e7, cval[7]);
     }
     __builtin_amdgcn_wave_barrier();
+    PHP_MARK(7);
 }
 
 // after the owners' sums: the S words of the caller's two bins are cleared for the next batch
@@ -496,8 +512,11 @@ __device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4
 // steps 1-4 of the file header; the record goes to `rec` (and `hrec`).  Everything about the keypoint is wave uniform.
 template <bool MAPS>
 __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const float4 kq, int aux, KpRecord *rec, KpRecord *hrec,
-                                              DescRowLds &L, const double *fold, const DescRoute &rt, const float4 *pool4, int lane) {
+                                              DescRowLds &L, const double *fold, const DescRoute &rt, const float4 *pool4, int lane PH_PARAM) {
     {
+#ifdef SIFT_PHASE_CLOCK
+        PhaseClock &ph = *php;
+#endif
         DescWindow w;
         int R;
         desc_window<MAPS>(tab, kq, aux, w, R);
@@ -524,6 +543,8 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
         auto above_lo = [&](float u) { return thr_ok ? (u > t_lo) : (g(u) > -1.0f); };
         w.fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;      // no under / overflow in div_by_reciprocal
 
+        PH_COUNT(13);
+        PH_MARK(1);
         // ---- 1b. row intervals: lane l owns the window rows l, l + 64, ...
         const bool rdec = sine >= 0.0f;          // u_r non-increasing in jj
         const bool cdec = !(cosine >= 0.0f);     // u_c non-increasing in jj
@@ -562,6 +583,7 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
         if (lane < 4) L.row_pack[S + lane] = ~0u;
         const int total = carry;
         __builtin_amdgcn_wave_barrier();
+        PH_MARK(2);
 
         // ---- 2 + 3. 64 ranks at a time.  Two forms of the loop (SIFT_DESC_PIPE); the product build uses the plain one.
         //      SOFTWARE-PIPELINED form (built in round 4 on the hypothesis that the launch is bound by the LDS round trips of
@@ -714,30 +736,61 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
         }
 #else
         int rcur = 0;                    // row of this lane's current rank (ranks only grow)
+        unsigned rword = L.row_pack[0];  // ... and its packed (start, first jj)
         DescSample nxt;
-        // a lane beyond the last rank evaluates the last sample again, aimed at its dummy entry: no divergence, no
-        // default values to materialise
+        // The row of a rank: ranks grow by 64 per batch, rows hold 20-70 samples, so a lane moves on by one to three rows per
+        // batch.  The packed words of the FOUR rows after the current one are requested a whole batch before they are
+        // needed (a search that read a row, compared and read the next was a chain of dependent LDS round trips at the
+        // head of every batch: a quarter of a wave's time, tools/dev/phase_clock.py); a lane whose rank lies further on --
+        // the short rows at a window corner -- looks again (wave uniform, rare).
+        // A lane beyond the last rank evaluates the last sample again, aimed at its dummy entry: no divergence, no
+        // default values to materialise.
+        unsigned wd[4];
+        auto row_request = [&]() {
+            wd[0] = L.row_pack[rcur + 1]; wd[1] = L.row_pack[rcur + 2]; wd[2] = L.row_pack[rcur + 3]; wd[3] = L.row_pack[rcur + 4];
+        };
         auto fetch = [&](int s0) {
             const int sc = min(s0 + lane, total - 1);
-            while (sc >= (int)(L.row_pack[rcur + 1] >> 8)) rcur++;
-            const unsigned rw = L.row_pack[rcur];
-            const int ii = rcur - R, jj = (int)(rw & 0xffu) - 128 + (sc - (int)(rw >> 8));
+            const unsigned lim = (unsigned)(sc + 1) << 8;
+            bool more = true;
+            for (;;) {
+                const bool a0 = wd[0] < lim, a1 = wd[1] < lim, a2 = wd[2] < lim, a3 = wd[3] < lim;
+                if (more) {
+                    rword = a3 ? wd[3] : (a2 ? wd[2] : (a1 ? wd[1] : (a0 ? wd[0] : rword)));
+                    rcur += (int)a0 + (int)a1 + (int)a2 + (int)a3;
+                }
+                more = more && a3;
+                if (!__ballot(more)) break;
+                row_request();
+            }
+            const int ii = rcur - R, jj = (int)(rword & 0xffu) - 128 + (sc - (int)(rword >> 8));
             if (w.interior) desc_fetch<true, MAPS>(w, ii, jj, nxt);
             else desc_fetch<false, MAPS>(w, ii, jj, nxt);
+            row_request();               // for the batch after this one
         };
+        row_request();
         if (total > 0) fetch(0);
+        PH_MARK(3);
         for (int s0 = 0; s0 < total; s0 += 64) {
             const DescSample cur = nxt;
             if (s0 + 64 < total) fetch(s0 + 64);     // wave uniform: the next batch's neighbours, in flight during this one
+#ifdef SIFT_PHASE_CLOCK
+            PH_COUNT(14);
+            PH_MARK(3);
+            if (s0 + 64 < total) { if (MAPS) PH_WAIT_VM(2); else PH_WAIT_VM(4); } else PH_WAIT_VM(0);
+            PH_MARK(4);
+#endif
             unsigned tgs[4], tgt[8];
             float cval[8];
             if (w.interior) desc_eval<true, MAPS>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
             else desc_eval<false, MAPS>(w, cur, s0 + lane < total, fold, rt, tgs, tgt, cval);
+            PH_MARK(5);
             int base_a, pa, pb;
-            desc_route(L.P, rt, tgs, tgt, cval, lane, base_a, pa, pb);
+            desc_route(L.P, rt, tgs, tgt, cval, lane, base_a, pa, pb PH_PASS);
             // ---- 3d. ordered sums of this lane's two bins
             desc_sum_pair(pool4, base_a >> 2, pa >> 2, pb >> 2, acc0, acc1);
             __builtin_amdgcn_wave_barrier();
+            PH_MARK(8);
             desc_route_reset(L.P, lane);
             __builtin_amdgcn_wave_barrier();
         }
@@ -777,6 +830,7 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
         const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
         store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.P.pool));
+        PH_MARK(9);
     }
 }
 
@@ -790,9 +844,14 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
                                                  const int *__restrict__ order) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
+#ifdef SIFT_PHASE_CLOCK
+    PhaseClock ph;
+    ph.start(L.ph, lane);
+#endif
     siftmath::load_atan_fold(fold);
     desc_pool_init(L.P, lane);
     __syncthreads();                     // the only workgroup barrier: the fold table
+    PH_MARK(0);
     const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
     const DescRoute rt = desc_route_of(L.P, lane);
     const float4 *pool4 = reinterpret_cast<const float4 *>(L.P.pool);
@@ -801,7 +860,9 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         if (!next) return i + nwaves;
         int t = 0;
         if (lane == 0) t = atomicAdd(next, 1);
-        return start + nwaves + __builtin_amdgcn_readfirstlane(t);
+        t = __builtin_amdgcn_readfirstlane(t);
+        PH_MARK(10);
+        return start + nwaves + t;
     };
     for (int t = start + gwave; t < end; t = advance(t)) {
         // hand-out position t -> keypoint i: list order, or the order mark_group_kernel prepared (largest windows first)
@@ -819,8 +880,11 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
             store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.P.pool));
             continue;
         }
-        desc_one_wave<MAPS>(tab, kq, aux, rec, hrec, L, fold, rt, pool4, lane);
+        desc_one_wave<MAPS>(tab, kq, aux, rec, hrec, L, fold, rt, pool4, lane PH_PASS);
     }
+#ifdef SIFT_PHASE_CLOCK
+    ph.flush(16, lane);
+#endif
 }
 
 #ifdef SIFT_DEV_VARIANTS
@@ -876,7 +940,7 @@ __device__ __forceinline__ void fused_waves(const OctaveTable &tab, float ori_si
             if (i >= out_capacity) { if (lane == 0) cnt->overflow = 1; break; }
             const float4 kq = make_float4(ox, oy, os, uni(peaks[q]));
             KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
-            desc_one_wave<MAPS>(tab, kq, aux, records + i, hrec, L, fold, rt, pool4, lane);
+            desc_one_wave<MAPS>(tab, kq, aux, records + i, hrec, L, fold, rt, pool4, lane PH_NONE);
         }
     }
     if (lane == 0 && made) atomicAdd(&cnt->grp_made[group], made);
@@ -1006,7 +1070,7 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
                     else { desc_fetch<false, MAPS>(w, ii, jj, q); desc_eval<false, MAPS>(w, q, s < total, fold, rt, tgs, tgt, cval); }
                 }
                 int base_a, pa, pb;
-                desc_route(P, rt, tgs, tgt, cval, lane, base_a, pa, pb);
+                desc_route(P, rt, tgs, tgt, cval, lane, base_a, pa, pb PH_NONE);
                 desc_route_reset(P, lane);           // (the owners below read the published entries, not S)
             }
             __syncthreads();

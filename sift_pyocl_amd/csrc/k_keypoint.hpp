@@ -189,6 +189,46 @@ __device__ __forceinline__ void store_record(KpRecord *dev, KpRecord *host, cons
     __builtin_amdgcn_wave_barrier();
 }
 
+// DEVELOPMENT INSTRUMENT (-DSIFT_PHASE_CLOCK, tools/dev/phase_clock.py): where a wave of the per-keypoint kernels spends
+// its time.  Lane 0 adds the shader-clock cycles since the previous mark to the phase's accumulator in the wave's LDS;
+// reading the clock waits for the wave's outstanding LDS / scalar-memory operations, so a phase is charged with the
+// latencies it started.  Accumulators [0, 12): cycles per phase, [12]: wave time, [13]: keypoints, [14]: batches; the
+// waves add theirs to g_phase (+16 per kernel: 0 orientation, 16 descriptor) and keep the longest wave in [15].
+#ifdef SIFT_PHASE_CLOCK
+__device__ unsigned long long g_phase[32];
+struct PhaseClock {
+    unsigned long long t, t0;
+    unsigned long long *acc;
+    __device__ __forceinline__ void start(unsigned long long *lds16, int lane) {
+        acc = lds16;
+        if (lane < 16) lds16[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        t0 = t = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int k, int lane) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        // (an LDS add without return: nothing of the instrument is waited for but the clock itself)
+        if (lane == 0) (void)__hip_atomic_fetch_add(acc + k, now - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = now;
+    }
+    __device__ __forceinline__ void count(int k, int lane) { if (lane == 0) (void)__hip_atomic_fetch_add(acc + k, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ void flush(int base, int lane) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (lane == 0) acc[12] = now - t0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 15) atomicAdd(&g_phase[base + lane], acc[lane]);
+        if (lane == 15) atomicMax(&g_phase[base + 15], acc[12]);
+    }
+};
+#define PH_MARK(k) ph.mark((k), lane)
+#define PH_COUNT(k) ph.count((k), lane)
+#define PH_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#else
+#define PH_MARK(k)
+#define PH_COUNT(k)
+#define PH_WAIT_VM(n)
+#endif
+
 #ifdef SIFT_ABLATE
 __device__ int g_ablate = 0;   // dev builds only: 1 skip phase 3, 2 skip atan2/exp, 3 refill only
 #define ABL(x) (g_ablate == (x))
@@ -212,6 +252,9 @@ struct alignas(16) OriWaveLds {
     unsigned mbase[36];
     float4 obuf[SIFT_ORI_OBUF];    // oriented keypoints waiting for their slots in the global list
     int oaux[SIFT_ORI_OBUF];
+#ifdef SIFT_PHASE_CLOCK
+    unsigned long long ph[16];
+#endif
 };
 
 __device__ __forceinline__ int wave_prefix_incl(int x) {      // inclusive prefix sum over the 64 lanes (DPP, no LDS)
@@ -253,9 +296,14 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
     const int count = n - first;
     const int nblocks = min((int)gridDim.x, count < 16384 ? small_blocks : (count < 65536 ? max(1024, small_blocks) : 4096));
     if ((int)blockIdx.x >= nblocks) return;
+#ifdef SIFT_PHASE_CLOCK
+    PhaseClock ph;
+    ph.start(L.ph, lane);
+#endif
     siftmath::load_atan_fold(fold);
     if (lane < 36) L.mask[lane] = make_uint2(0u, 0u);
     __syncthreads();
+    PH_MARK(0);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (nblocks * blockDim.x) >> 6;
     if (threadIdx.x == 0 && blockIdx.x == 0 && cnt->n_kp > kp_capacity) cnt->overflow = 1;
@@ -325,12 +373,19 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         bool nvalid = locate(boff, nr, nc);
         GradTaps ntaps = {};
         if (nvalid) ntaps = taps_at(nc, nr);   // the loads of batch b+1 are issued before batch b is evaluated
+        PH_COUNT(13);
+        PH_MARK(1);
         for (int base = 0; base < total; base += bstep) {         // (workgroup uniform in team form)
             bool valid = nvalid;
             const int r = nr, c = nc;
             const GradTaps taps = ntaps;
             nvalid = locate(base + bstep + boff, nr, nc);
             if (nvalid) ntaps = taps_at(nc, nr);
+#ifdef SIFT_PHASE_CLOCK
+            PH_COUNT(14);
+            if (base + bstep + boff < total) PH_WAIT_VM(4); else PH_WAIT_VM(0);
+            PH_MARK(2);
+#endif
             int bin = 0;
             float val = 0.0f;
             if (valid) {
@@ -361,6 +416,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 if (valid) atomicOr(reinterpret_cast<unsigned *>(L.mask) + 2 * bin + (lane >> 5), 1u << (lane & 31));
             }
             __builtin_amdgcn_wave_barrier();
+            PH_MARK(3);
             // owners: vote counts -> aligned pool segments
             const uint2 mine = (lane < 36) ? L.mask[lane] : make_uint2(0u, 0u);
             const int votes = __popc(mine.x) + __popc(mine.y);
@@ -371,6 +427,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             // sums) and the owners' loops need no per-element masks
             if (votes) reinterpret_cast<float4 *>(L.pool)[(seg + padded - 4) >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
             __builtin_amdgcn_wave_barrier();
+            PH_MARK(4);
             // voters: value to segment base + rank among the voters of the same bin (mbcnt: set bits below this lane)
             {
                 const uint2 mk = L.mask[bin];
@@ -379,6 +436,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 if (valid) L.pool[pos] = val;
             }
             __builtin_amdgcn_wave_barrier();
+            PH_MARK(5);
             if (!team) {
                 // owners: ordered sum of the segment
                 for (int k0 = 0; k0 < padded; k0 += 4) {
@@ -387,6 +445,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                 }
                 if (votes) L.mask[lane] = make_uint2(0u, 0u);
                 __builtin_amdgcn_wave_barrier();
+                PH_MARK(6);
             } else {
                 __syncthreads();
                 if (w4 == 0 && lane < 36) {
@@ -458,6 +517,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             L.oaux[at] = aux;
         }
         pending += nmain + nextra;
+        PH_MARK(7);
     }
     // ---- the workgroup's remaining entries leave with a single atomicAdd
     if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
@@ -473,6 +533,10 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
         for (int q = 0; q < w; q++) slot += s_pending[q];
         store_pending(slot, pending);
     }
+#ifdef SIFT_PHASE_CLOCK
+    PH_MARK(8);
+    ph.flush(0, lane);
+#endif
 }
 
 #ifdef SIFT_DEV_VARIANTS

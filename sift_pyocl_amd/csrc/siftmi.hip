@@ -750,6 +750,16 @@ void launch_describe_group(siftmi_plan *p, int group, hipStream_t st, hipEvent_t
 extern "C" {
 
 const char *siftmi_last_error(void) { return g_err.c_str(); }
+#ifdef SIFT_PHASE_CLOCK
+// development instrument (k_keypoint.hpp: PhaseClock): the 32 accumulators of the per-keypoint kernels; reset != 0 clears them
+int siftmi_dev_phase(uint64_t *out32, int32_t reset) {
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(siftk::g_phase), sizeof h) != hipSuccess) return fail(SIFTMI_EDEVICE, "phase clock read failed");
+    if (out32) for (int i = 0; i < 32; i++) out32[i] = h[i];
+    if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(siftk::g_phase), h, sizeof h) != hipSuccess) return fail(SIFTMI_EDEVICE, "phase clock reset failed"); }
+    return SIFTMI_OK;
+}
+#endif
 const char *siftmi_version(void) { return "sift_pyocl_amd 0.1 (gfx950)"; }
 
 #ifdef SIFT_ABLATE

@@ -120,7 +120,9 @@ struct Options {
     int mm_blocks = 256;     // few, fat workgroups: every block ends with two atomics on the same cache line
     int mm_threads = 1024;   // threads per workgroup of the f32 min/max pass: sixteen waves per workgroup = four per SIMD at the same 256 atomic pairs
                              // (256 threads: one wave per SIMD; three interleaved A/B runs 0.7924-0.7934 -> 0.7863-0.7876 ms, 512^2 0.2561 -> 0.2531)
-    int desc_team = 1024;    // groups with fewer oriented keypoints than this are described by descriptor_team_kernel (0: never); measured cross-over 1000-1800 (one workgroup slot per keypoint: 4 per CU)
+    int desc_team = 2048;    // groups with fewer oriented keypoints than this are described by the workgroup-per-keypoint form (0: never); measured cross-over
+                             // 1000-1800 alone (one workgroup slot per keypoint: 4 per CU); in a frame, round 4 (interleaved A/B, 1024 / 2048 / 3072 / 4096):
+                             // 1024^2 smoothed 0.588 / 0.568 / 0.568 / 0.570 ms, 2048^2 white 0.500 / 0.499 / 0.520 / 0.521, headline and the other frames equal
     int desc_sort = 0;       // groups of at most this many oriented keypoints (<= 16384) are described largest window first (0: list order).
                              // Round 3 (16384): headline 0.818 -> 0.809 ms; round 4, after the descriptor kernel's per-keypoint set-up was
                              // cut: list order 0.802-0.809 against 0.811-0.815 ordered (three interleaved A/B runs; 9 octaves 0.961 / 0.969,

@@ -1,11 +1,17 @@
-"""dev: where the waves of the per-keypoint kernels spend their time (library built with -DSIFT_PHASE_CLOCK as
-sift_pyocl_amd/libsiftmi_ph.so; k_keypoint.hpp: PhaseClock).  python tools/dev/phase_clock.py [size] [white|smooth] [octaves] [name=value ...]"""
+"""dev: where the waves of the per-keypoint kernels spend their time (a build of the library with -DSIFT_PHASE_CLOCK, made
+on first use as /tmp/libsiftmi_ph.so; k_keypoint.hpp: PhaseClock).  python tools/dev/phase_clock.py [size] [white|smooth] [octaves] [name=value ...]"""
 import os, sys, shutil, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = os.path.join(ROOT, "sift_pyocl_amd")
+ph = "/tmp/libsiftmi_ph.so"
+if not os.path.exists(ph):      # the instrumented build (30 s): never kept inside the package
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                           "-fhip-fp32-correctly-rounded-divide-sqrt", "-DSIFT_PHASE_CLOCK", os.path.join(pkg, "csrc", "siftmi.hip"), "-o", ph],
+                          stderr=subprocess.DEVNULL)
 shutil.copy(os.path.join(pkg, "libsiftmi.so"), "/tmp/libsiftmi_keep.so")
-shutil.copy(os.path.join(pkg, "libsiftmi_ph.so"), os.path.join(pkg, "libsiftmi.so"))
+shutil.copy(ph, os.path.join(pkg, "libsiftmi.so"))
 try:
     import numpy as np, torch
     import sift_pyocl_amd as sp

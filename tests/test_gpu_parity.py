@@ -259,6 +259,75 @@ def test_detection_stages(siftlib, oracle, maker, shape):
         assert np.array_equal(dd, edesc[valid]), "descriptor bins differ at scale %d" % s
 
 
+@pytest.mark.parametrize("octsize", [1, 2])
+def test_descriptor_windows_at_their_edges(siftlib, oracle, octsize):
+    """Descriptor stage on SYNTHETIC oriented keypoints chosen to stress the row-interval form of the kernel (k_descriptor.hpp):
+    window axes on and a hair off the pixel axes and diagonals (rows that start / end exactly on a cell boundary, the short rows
+    at the corners of a 45-degree window: the row look-up moves on by more than four rows per batch there), the smallest and the
+    largest window the row tables hold (R = 127), centres on, next to and beyond the plane's borders (clipped rows, empty rows,
+    empty windows), sub-pixel offsets of exactly one half.  Bit-identical bins against the oracle."""
+    H, W = 300, 421
+    img = smooth_noise((H, W))
+    blurs = _octave_blurs(oracle, img)
+    s = 2
+    eg, eo = oracle.gradient(blurs[s])
+    pi = float(np.float32(np.pi))
+    angles = []
+    for a in (0.0, pi / 4, pi / 2, 3 * pi / 4, pi, -pi / 4, -pi / 2, -3 * pi / 4, -pi):
+        for eps in (0.0, 1e-6, -1e-6, 1e-3):
+            angles.append(np.float32(a + eps))
+    angles += [np.float32(0.3), np.float32(-2.9), np.float32(1.1), np.float32(2.5)]
+    sigmas = [0.8, 1.6, 2.2, 3.17, 4.5, 7.0, 11.9]          # window radius 4 ... 126 pixels of the octave
+    centres = [(210.0, 150.0), (210.5, 150.5), (3.0, 4.0), (0.0, 0.0), (W - 1.0, H - 1.0), (W - 2.5, 40.25), (60.75, H - 1.5),
+               (-6.0, 100.0), (W + 9.0, H + 9.0), (200.0, -3.0)]
+    rows = []
+    k = 0
+    for sg in sigmas:
+        for (cx, cy) in centres:
+            for j in range(4):
+                ang = angles[k % len(angles)]; k += 1
+                rows.append((cx * octsize, cy * octsize, sg * octsize, ang))
+    for ang in angles:                                      # every angle once on the mid-size window in the middle of the plane
+        rows.append((123.25 * octsize, 77.75 * octsize, 2.9 * octsize, ang))
+    kk = np.ascontiguousarray(np.array(rows, np.float32))
+    want = oracle.descriptor(kk, eg, eo, octsize, 0, len(kk))
+    ss = np.full(len(kk), s, np.int32)
+    got = np.zeros((len(kk), 128), np.uint8)
+    assert siftlib.siftmi_stage_descriptor(0, _p(blurs), W, H, octsize, _p(kk), _p(ss), len(kk), _p(got)) == 0
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, "descriptor bins differ for keypoints %s: %s" % (bad[:8], kk[bad[:8]])
+    assert want.any(axis=1).sum() > len(kk) // 2            # (most of these windows do hold samples)
+
+
+def test_orientation_windows_at_the_borders(siftlib, oracle):
+    """Orientation stage on SYNTHETIC refined keypoints: windows clipped by every border and corner, the smallest and the
+    largest radii a plan can produce and beyond (sigma 0.5 ... 8: radius 2 ... 36), centres on half-pixel positions.  Same
+    oriented list (as a set: slots are handed out by an atomic counter) as the oracle, bit for bit."""
+    H, W = 300, 421
+    img = multiscale_noise((H, W))
+    blurs = _octave_blurs(oracle, img)
+    par = _params()
+    opar = oracle.default_params()
+    s = 1
+    eg, eo = oracle.gradient(blurs[s])
+    rows = []
+    for sg in (0.5, 1.0, 1.6, 2.5, 4.5, 8.0):
+        for (r, c) in [(150.0, 210.0), (150.5, 210.5), (0.0, 0.0), (1.0, 2.0), (H - 1.0, W - 1.0), (H - 2.0, 3.0), (5.25, W - 1.75),
+                       (H / 2.0, 0.0), (0.0, W / 2.0), (H - 1.0, W / 2.0), (77.75, 123.25)]:
+            rows.append((12.0, r, c, sg))
+    sel = np.ascontiguousarray(np.array(rows, np.float32))
+    buf = np.full((len(sel) * 8 + 8, 4), -1, np.float32); buf[:len(sel)] = sel
+    okp, cnt = oracle.orientation(buf, eg, eo, 1, 0, len(sel), capacity=len(buf), par=opar)
+    okp = okp[:cnt]
+    valid = ~np.isnan(okp.sum(axis=1))
+    scl = np.full(len(sel), s, np.int32)
+    out = np.empty((len(buf), 4), np.float32); osc = np.empty(len(buf), np.int32); no = C.c_int64()
+    assert siftlib.siftmi_stage_orientation(0, _p(blurs), W, H, 1, _p(sel), _p(scl), len(sel), C.byref(par), _p(out), _p(osc),
+                                            len(buf), C.byref(no)) == 0
+    assert no.value == valid.sum() and no.value >= len(sel) // 2
+    assert np.array_equal(sort_rows(out[:no.value]).view(np.uint32), sort_rows(okp[valid]).view(np.uint32))
+
+
 def test_shrink_and_convert(siftlib):
     img = white_noise((301, 203), 2)
     out = np.empty((150, 101), np.float32)

@@ -299,6 +299,31 @@ def test_descriptor_windows_at_their_edges(siftlib, oracle, octsize):
     assert want.any(axis=1).sum() > len(kk) // 2            # (most of these windows do hold samples)
 
 
+@pytest.mark.parametrize("seed,octsize,shape", [(1, 1, (300, 421)), (2, 4, (257, 330)), (3, 1, (97, 131))])
+def test_descriptor_random_keypoints(siftlib, oracle, seed, octsize, shape):
+    """3000 random oriented keypoints per case (uniform centres up to 8 pixels beyond the plane, log-uniform sigma from the
+    smallest window to R = 126, uniform angle in [-pi, pi]): the descriptor stage against the oracle, every bin."""
+    H, W = shape
+    rng = np.random.default_rng(seed)
+    img = multiscale_noise((H, W)) if seed != 2 else white_noise((H, W))
+    blurs = _octave_blurs(oracle, img)
+    s = 1 + seed % 3
+    eg, eo = oracle.gradient(blurs[s])
+    n = 3000
+    kk = np.empty((n, 4), np.float32)
+    kk[:, 0] = rng.uniform(-8, W + 8, n) * octsize
+    kk[:, 1] = rng.uniform(-8, H + 8, n) * octsize
+    kk[:, 2] = np.exp(rng.uniform(np.log(0.4), np.log(11.9), n)) * octsize
+    kk[:, 3] = rng.uniform(-np.pi, np.pi, n)
+    kk[::97, 3] = np.float32(np.pi); kk[1::97, 3] = -np.float32(np.pi); kk[2::97, 3] = 0.0
+    want = oracle.descriptor(kk, eg, eo, octsize, 0, n)
+    ss = np.full(n, s, np.int32)
+    got = np.zeros((n, 128), np.uint8)
+    assert siftlib.siftmi_stage_descriptor(0, _p(blurs), W, H, octsize, _p(kk), _p(ss), n, _p(got)) == 0
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, "descriptor bins differ for %d keypoints, first %s" % (len(bad), kk[bad[:4]])
+
+
 def test_orientation_windows_at_the_borders(siftlib, oracle):
     """Orientation stage on SYNTHETIC refined keypoints: windows clipped by every border and corner, the smallest and the
     largest radii a plan can produce and beyond (sigma 0.5 ... 8: radius 2 ... 36), centres on half-pixel positions.  Same

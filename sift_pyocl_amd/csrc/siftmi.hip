@@ -110,7 +110,9 @@ struct Options {
     // frame 0.760 ms, with 896-960 workgroups 0.671; 2048^2 smooth 1.85 -> 1.73), bytes of dynamic LDS (residency throttle)
     int desc_blocks = 960, desc_pad = 0;
     int desc_small_blocks = 576;   // ... and for groups of fewer than 16384 (the later octaves' chain needs the room)
-    int desc_dense_blocks = 832;   // ... and for groups of >= 65536 keypoints (704: 5.47 ms per 154 k-keypoint call, 768-896: 5.27, 960: 5.31)
+    int desc_dense_blocks = 960;   // ... and for groups of >= 65536 keypoints (lazy-gradient form; the MAPS form always takes desc_blocks).  Round 3: 832
+                                   // (704: 5.47 ms per 154 k-keypoint call, 768-896: 5.27, 960: 5.31); round 4, with 2 KB less LDS per workgroup and the
+                                   // row look-ahead: 832 / 896 / 960 -> 154 k keypoints without maps 4.56 / 4.49 / 4.42 ms, 16384^2 10.64 / 10.55 / 10.50
     int desc_stream = 0;     // 1: force the streaming form of the descriptor kernel (any window size)
     // Full gradient maps (gradient_maps_kernel) for the per-keypoint kernels: 0 never, 1 always, 2 when the previous image
     // of this plan had at least one oriented keypoint per `maps_density` pixels in the group (octave 0 / the later octaves).

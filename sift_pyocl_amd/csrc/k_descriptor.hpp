@@ -12,9 +12,12 @@
 //     out of the search: g(u) = u / spacing + 1.5f is non-decreasing in u, hence g(u) < 4 <=> u < t_hi and
 //     g(u) > -1 <=> u > t_lo for two float thresholds found once per keypoint by stepping to the exact flip points of g
 //     (verified; the search falls back to evaluating g when the verification fails, e.g. non-finite spacing).  One lane
-//     per row bisects the four flips on the exact float expression of u, a wave prefix sum turns the run lengths into
-//     the raster rank of every in-window sample.  (The streaming form tests all (2R+1)^2 positions, half of which lie
-//     outside the rotated window, and re-packs its sample list every 64 samples: a quarter of its time.)
+//     per row locates the four flips on the exact float expression of u (a closed-form bracket of four evaluations around
+//     the real crossing; bisection where the bracket finds no step), a wave prefix sum turns the run lengths into the raster
+//     rank of every in-window sample; a row's (first rank, first column) is one packed word of the wave's row table, and a
+//     lane finds the row of its rank among four words requested a batch ahead.  (The streaming form tests all (2R+1)^2
+//     positions, half of which lie outside the rotated window, and re-packs its sample list every 64 samples: a quarter
+//     of its time.)
 //  2. EVALUATION.  64 consecutive ranks at a time, one sample per lane: gradient magnitude / orientation from
 //     blur[scale] (image.cl:58-77), Gaussian weight, the eight (bin, value) contributions.  atan2 / exp go through the
 //     Ziv fast paths of siftmath.hpp (bit-identical to the defining functions).

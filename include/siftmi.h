@@ -83,16 +83,23 @@ const char *siftmi_version(void);
 int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t device_id,
                        const siftmi_params *params, int32_t profile, siftmi_plan **out);
 int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsize, int64_t *bytes_allocated);
+/* Capacity as the reference (plan.py:243, 797-804): kpsize = H*W / PIX_PER_KP entries PER OCTAVE -- for the candidates of a
+ * detection scale appended behind the octave's oriented keypoints so far, and for those oriented keypoints.  An image within
+ * that rule returns every record (up to n_octaves * kpsize of them); one beyond it raises `overflow` and keeps at most kpsize
+ * records of each octave (the reference silently drops whatever its atomic counter places beyond the buffer, image.cl:203-205).
+ * The device lists start at kpsize entries and grow when an image needs more (it is then run again inside the same call):
+ * siftmi_plan_capacity reports the record list's current size and how often a list has grown. */
+int siftmi_plan_capacity(const siftmi_plan *plan, int64_t *records, int64_t *growths);
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
- *   launch shapes      "march", "team", "march_nt", "march_wgs", "march_nb", "tile", "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
+ *   launch shapes      "march", "march_wgs", "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
  *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks",
- *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_sort", "desc_sort_density",
- *                      "desc_stream", "maps_blocks"
+ *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_bucket" (groups below that many
+ *                      keypoints are described detection scale 3 first; 0: list order), "desc_stream", "maps_blocks"
  *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",
  *                      "maps" (0 never / 1 always / 2 by the previous image's count), "maps_density"
- *   stream schedule    "overlap", "chain0", "early_pyr", "split_detect", "spin"
+ *   stream schedule    "overlap" (0: one stream), "split0" (octave 0 of a large frame in two groups: scale 1 from plane 3 on), "spin"
  *   diagnostics        "host_timing", "tail_fault" (treat the next n tail launches as timed out: exercises the re-run path) */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 /* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from

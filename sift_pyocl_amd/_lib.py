@@ -43,6 +43,7 @@ _SIGNATURES = {
     "siftmi_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "siftmi_plan_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "siftmi_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "siftmi_plan_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "siftmi_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
     "siftmi_host_free": (C.c_int, [C.c_void_p]),
     "siftmi_plan_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,

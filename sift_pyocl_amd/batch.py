@@ -145,7 +145,7 @@ class BatchPlan(SiftPlan):
                                                      caps if direct else None, counts, offsets, C.byref(parked), C.byref(ovf)))
             self.overflow = bool(ovf.value)
             if self.overflow:
-                logger.warning("Keypoint counter overflow: more than %s keypoints in a frame, result truncated", self.kpsize)
+                logger.warning("Keypoint counter overflow: an octave of a frame needs more than %s entries, result cut to that per octave", self.kpsize)
             flat = numpy.empty(0, dtype=self.dtype_kp)      # a batch of blank frames parks nothing
             if parked.value:
                 flat = numpy.empty(parked.value, dtype=self.dtype_kp)

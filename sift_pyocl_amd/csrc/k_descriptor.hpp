@@ -49,12 +49,6 @@
 namespace siftk {
 
 #define SIFT_DESC_MAXRAD 127
-#ifndef SIFT_DESC_PIPE
-#define SIFT_DESC_PIPE 0       // 1: software-pipelined batch loop of the wave-per-keypoint form (desc_one_wave; needs SIFT_DESC_WAVES 3).
-                               // Bit-identical; measured no faster (round 4, interleaved A/B of the two builds): group 0 of the headline
-                               // frame alone 0.279 against 0.282-0.298 ms, 154 k keypoints 2.68 against 2.49 ms (three waves per SIMD
-                               // instead of four), whole headline call 0.818 against 0.796 ms -- see the loop's comment
-#endif
 #ifndef SIFT_DESC_WAVES
 #define SIFT_DESC_WAVES 4      // 128 VGPRs, no scratch: 4.03 ms against 4.44 ms at 5 waves (96 VGPRs, 76 B of scratch) on 154 k keypoints
 #endif
@@ -512,9 +506,9 @@ __device__ __forceinline__ void desc_window(const OctaveTable &tab, const float4
 }
 
 // One oriented keypoint (x, y, sigma*oct, angle), detection scale | octave << 8 in `aux`, described by the calling WAVE:
-// steps 1-4 of the file header; the record goes to `rec` (and `hrec`).  Everything about the keypoint is wave uniform.
+// steps 1-4 of the file header; the record is number `rec_i` of the group's block (store_record).  Everything about the keypoint is wave uniform.
 template <bool MAPS>
-__device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const float4 kq, int aux, KpRecord *rec, KpRecord *hrec,
+__device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const float4 kq, int aux, const RecordSink *sink, int rec_i,
                                               DescRowLds &L, const double *fold, const DescRoute &rt, const float4 *pool4, int lane PH_PARAM) {
     {
 #ifdef SIFT_PHASE_CLOCK
@@ -609,135 +603,6 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
         //      LDS latency, and the pipelined loop does not have fewer instructions.  More waves or fewer instructions move
         //      this launch; overlap inside a wave does not.
         float acc0 = 0.0f, acc1 = 0.0f;  // bins lane and lane + 64
-#if SIFT_DESC_PIPE
-        int rcur = 0;                    // row of this lane's current rank (ranks only grow)
-        unsigned rword = L.row_pack[0];  // ... and its packed (start, first jj)
-        DescSample smp;                  // neighbours of the batch that is evaluated next
-        unsigned wd[4];
-        auto row_request = [&]() {
-            wd[0] = L.row_pack[rcur + 1]; wd[1] = L.row_pack[rcur + 2]; wd[2] = L.row_pack[rcur + 3]; wd[3] = L.row_pack[rcur + 4];
-        };
-        // the row of rank s0 + lane among the current one and the four requested (a lane whose rank lies further on -- the
-        // short rows at a window corner -- looks again: wave uniform, rare), then the four neighbours of that sample.
-        // A lane beyond the last rank takes the last sample again, aimed at its dummy entry: no divergence, no defaults.
-        auto row_resolve_fetch = [&](int s0) {
-            const int sc = min(s0 + lane, total - 1);
-            const unsigned lim = (unsigned)(sc + 1) << 8;
-            bool more = true;
-            for (;;) {
-                const bool a0 = wd[0] < lim, a1 = wd[1] < lim, a2 = wd[2] < lim, a3 = wd[3] < lim;
-                if (more) {
-                    rword = a3 ? wd[3] : (a2 ? wd[2] : (a1 ? wd[1] : (a0 ? wd[0] : rword)));
-                    rcur += (int)a0 + (int)a1 + (int)a2 + (int)a3;
-                }
-                more = more && a3;
-                if (!__ballot(more)) break;
-                row_request();
-            }
-            const int ii = rcur - R, jj = (int)(rword & 0xffu) - 128 + (sc - (int)(rword >> 8));
-            if (w.interior) desc_fetch<true, MAPS>(w, ii, jj, smp);
-            else desc_fetch<false, MAPS>(w, ii, jj, smp);
-        };
-        unsigned tgs[4], tgt[8];
-        float cval[8];
-        DescEvalState st;
-        if (total > 0) {
-            // prologue: batch 0 evaluated, batch 1's neighbours requested
-            row_request(); row_resolve_fetch(0);
-            if (w.interior) desc_eval1<true, MAPS>(w, smp, st); else desc_eval1<false, MAPS>(w, smp, st);
-            desc_eval2<MAPS>(st, fold);
-            desc_eval3<MAPS>(st);
-            desc_eval4(w, st, lane < total, rt, tgs, tgt, cval);
-            row_request(); row_resolve_fetch(64);
-        }
-        const unsigned pool0 = desc_lds_addr(&L.P.pool[0]);
-        const int prev = (lane & ~7) | ((lane + 7) & 7);           // same cell, orientation bin - 1 (bins lane and lane + 64 alike)
-        for (int s0 = 0; s0 < total; s0 += 64) {
-            const bool have_next = s0 + 64 < total;                // wave uniform
-            // ---- R1
-            desc_or32<4 * SIFT_DESC_C0>(tgs[0], rt.bit); desc_or32<4 * SIFT_DESC_C1>(tgs[1], rt.bit);
-            desc_or32<4 * SIFT_DESC_C2>(tgs[2], rt.bit); desc_or32<4 * SIFT_DESC_C3>(tgs[3], rt.bit);
-            __builtin_amdgcn_wave_barrier();
-            const unsigned s_al = L.P.S[0][lane], s_alp = L.P.S[0][prev], s_ah = L.P.S[1][lane], s_ahp = L.P.S[1][prev];
-            const unsigned s_bl = L.P.S[0][lane + 64], s_blp = L.P.S[0][prev + 64], s_bh = L.P.S[1][lane + 64], s_bhp = L.P.S[1][prev + 64];
-            if (s0 + 128 < total) row_request();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- E1
-            if (have_next) { if (w.interior) desc_eval1<true, MAPS>(w, smp, st); else desc_eval1<false, MAPS>(w, smp, st); }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- R2: bin owners: mask = S[ob] | S[ob - 1] of the cell, counts, 16-byte aligned pool segments from a wave prefix sum
-            const unsigned alo = s_al | s_alp, ahi = s_ah | s_ahp, blo = s_bl | s_blp, bhi = s_bh | s_bhp;
-            const int cnta = __popc(alo) + __popc(ahi), cntb = __popc(blo) + __popc(bhi);
-            const int pa = (cnta + 3) & ~3, pb = (cntb + 3) & ~3;
-            const int base_a = wave_prefix_incl(pa + pb) - (pa + pb);
-            const int base_b = base_a + pa;
-            *reinterpret_cast<uint4 *>(&L.P.ent[lane]) = make_uint4(alo, ahi, pool0 + 4u * (unsigned)base_a, 0u);
-            *reinterpret_cast<uint4 *>(&L.P.ent[lane + 64]) = make_uint4(blo, bhi, pool0 + 4u * (unsigned)base_b, 0u);
-            // the last group of four of every segment starts as +0: its padding then adds +0 (an exact no-op on these
-            // non-negative sums), so the owners' loops need no per-element masks
-            if (cnta) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)base_b) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
-            if (cntb) *reinterpret_cast<desc_lds_f4 *>(pool0 - 16u + 4u * (unsigned)(base_b + pb)) = (desc_f4v){0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_wave_barrier();
-            if (s0 + 128 < total) row_resolve_fetch(s0 + 128);    // (after E1: `smp` is free again; before the entry reads: its row words arrived with the S words)
-            __builtin_amdgcn_sched_barrier(0);
-            const uint4 e0 = desc_entry<16 * SIFT_DESC_C0>(tgt[0]), e1 = desc_entry<16 * SIFT_DESC_C0>(tgt[1]);
-            const uint4 e2 = desc_entry<16 * SIFT_DESC_C1>(tgt[2]), e3 = desc_entry<16 * SIFT_DESC_C1>(tgt[3]);
-            const uint4 e4 = desc_entry<16 * SIFT_DESC_C2>(tgt[4]), e5 = desc_entry<16 * SIFT_DESC_C2>(tgt[5]);
-            const uint4 e6 = desc_entry<16 * SIFT_DESC_C3>(tgt[6]), e7 = desc_entry<16 * SIFT_DESC_C3>(tgt[7]);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- E2
-            if (have_next) desc_eval2<MAPS>(st, fold);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- R3: every value to segment start + 4 * rank among the contributors of its bin (mbcnt: set bits of the mask
-            //          below this lane); then the owners' first two groups of four
-            // (the count starts from the entry's fourth word, a zero: with every word of the 16-byte read in use the register
-            // allocator cannot hand a word of an entry still in flight to the evaluation stage -- a write to it would wait
-            // for the read, i.e. put the round trip back on the wave's path)
-            auto place = [&](const uint4 &en, float v) {
-                *reinterpret_cast<desc_lds_f32 *>(en.z + 4u * __builtin_amdgcn_mbcnt_hi(en.y, __builtin_amdgcn_mbcnt_lo(en.x, en.w))) = v;
-            };
-            place(e0, cval[0]); place(e1, cval[1]); place(e2, cval[2]); place(e3, cval[3]);
-            place(e4, cval[4]); place(e5, cval[5]); place(e6, cval[6]); place(e7, cval[7]);
-            __builtin_amdgcn_wave_barrier();
-            const int qa = base_a >> 2, ea = pa >> 2, eb = pb >> 2, qb = qa + ea;
-            const float4 a0 = pool4[ea > 0 ? qa : 224], a1 = pool4[ea > 1 ? qa + 1 : 224];
-            const float4 b0 = pool4[eb > 0 ? qb : 224], b1 = pool4[eb > 1 ? qb + 1 : 224];
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- E3
-            if (have_next) desc_eval3<MAPS>(st);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- R4: ordered sums of this lane's two bins (desc_sum_pair, its first reads issued above)
-            acc0 = desc_add(acc0, a0.x); acc1 = desc_add(acc1, b0.x);
-            acc0 = desc_add(acc0, a0.y); acc1 = desc_add(acc1, b0.y);
-            acc0 = desc_add(acc0, a0.z); acc1 = desc_add(acc1, b0.z);
-            acc0 = desc_add(acc0, a0.w); acc1 = desc_add(acc1, b0.w);
-            acc0 = desc_add(acc0, a1.x); acc1 = desc_add(acc1, b1.x);
-            acc0 = desc_add(acc0, a1.y); acc1 = desc_add(acc1, b1.y);
-            acc0 = desc_add(acc0, a1.z); acc1 = desc_add(acc1, b1.z);
-            acc0 = desc_add(acc0, a1.w); acc1 = desc_add(acc1, b1.w);
-            if (__ballot(ea > 2 || eb > 2)) {                 // wave uniform
-                const int nmax = max(ea, eb);
-                float4 va = pool4[ea > 2 ? qa + 2 : 224], vb = pool4[eb > 2 ? qb + 2 : 224];
-                for (int g4 = 2; g4 < nmax; g4++) {
-                    const float4 ca = va, cb = vb;
-                    va = pool4[(g4 + 1 < ea) ? qa + g4 + 1 : 224];
-                    vb = pool4[(g4 + 1 < eb) ? qb + g4 + 1 : 224];
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc0 = desc_add(acc0, ca.x); acc1 = desc_add(acc1, cb.x);
-                    acc0 = desc_add(acc0, ca.y); acc1 = desc_add(acc1, cb.y);
-                    acc0 = desc_add(acc0, ca.z); acc1 = desc_add(acc1, cb.z);
-                    acc0 = desc_add(acc0, ca.w); acc1 = desc_add(acc1, cb.w);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            desc_route_reset(L.P, lane);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- E4
-            if (have_next) desc_eval4(w, st, s0 + 64 + lane < total, rt, tgs, tgt, cval);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
         int rcur = 0;                    // row of this lane's current rank (ranks only grow)
         unsigned rword = L.row_pack[0];  // ... and its packed (start, first jj)
         DescSample nxt;
@@ -797,7 +662,6 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
             desc_route_reset(L.P, lane);
             __builtin_amdgcn_wave_barrier();
         }
-#endif
 
         // ---- 4. normalise, clamp at 0.2, renormalise, quantise (keypoints_cpu.cl:125-160): the reference sums the 128
         //         squares sequentially in index order; every lane repeats that sum from LDS (eight 16-byte reads in
@@ -832,7 +696,7 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
         // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see the oracle's note)
         const int i0 = (acc0 == acc0) ? (int)(512.0 * (double)acc0) : 0;
         const int i1 = (acc1 == acc1) ? (int)(512.0 * (double)acc1) : 0;
-        store_record(rec, hrec, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.P.pool));
+        store_record(sink, rec_i, kq, min(255, i0), min(255, i1), lane, reinterpret_cast<unsigned char *>(L.P.pool));
         PH_MARK(9);
     }
 }
@@ -840,11 +704,14 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
 // `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
 // after that it asks the counter, so that a wave with a small window does not idle while another still has two large
 // ones to go (windows differ by 4x in samples within an octave).
+// `ord` (null: list order): the group's three hand-out lists (k_keypoint.hpp: orientation_kernel), `ord_stride` entries apart,
+// holding n1 / n2 / n3 keypoints of detection scales 1 / 2 / 3.  Hand-out position u walks scale 3, then 2, then 1: a window
+// has 17 to 75 batches of samples and grows with the scale, so the launch ends on its smallest windows (in list order it
+// ended with whatever large windows were handed out last on an otherwise idle chip: the longest wave ran 2.4x the mean,
+// profiles/r04/phase_clock_white4096.txt).  Nothing is sorted: the orientation launch appends to the list of the scale.
 template <bool MAPS>
 __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
-                                                 int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
-                                                 int host_capacity, DescRowLds *lds_all, double *fold, int *next, int nblocks,
-                                                 const int *__restrict__ order) {
+                                                 int start, int end, const RecordSink *sink, DescRowLds *lds_all, double *fold, int *next, int nblocks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     DescRowLds &L = lds_all[wave];
 #ifdef SIFT_PHASE_CLOCK
@@ -868,8 +735,8 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         return start + nwaves + t;
     };
     for (int t = start + gwave; t < end; t = advance(t)) {
-        // hand-out position t -> keypoint i: list order, or the order mark_group_kernel prepared (largest windows first)
-        const int i = order ? __builtin_amdgcn_readfirstlane(order[t]) : t;
+        // hand-out position t -> keypoint i: list order, or scale 3 first
+        const int i = start + handout_index(sink, t - start);
         // the keypoint is the same in every lane: keep its integer attributes in scalar registers
         float4 kq = okp[i];              // (x, y, sigma*oct, angle)
         kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
@@ -877,78 +744,17 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         kq.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.z)));
         kq.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.w)));
         const int aux = __builtin_amdgcn_readfirstlane(oaux[i]);         // detection scale | octave << 8
-        KpRecord *rec = records + i;
-        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
         if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
-            store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.P.pool));
+            store_record(sink, i, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(L.P.pool));
             continue;
         }
-        desc_one_wave<MAPS>(tab, kq, aux, rec, hrec, L, fold, rt, pool4, lane PH_PASS);
+        desc_one_wave<MAPS>(tab, kq, aux, sink, i, L, fold, rt, pool4, lane PH_PASS);
     }
 #ifdef SIFT_PHASE_CLOCK
     ph.flush(16, lane);
 #endif
 }
 
-#ifdef SIFT_DEV_VARIANTS
-// DEVELOPMENT BUILDS ONLY -- measured slower than the separate launches on every frame (Options::fused_kp in siftmi.hip).
-// Orientation AND description of refined keypoints by one wave each (keypoint_fused_kernel): a wave takes refined keypoint t,
-// assigns its orientations (orient_wave: at most 36, nearly always one or two), reserves that many record slots with one
-// atomic and describes them one after the other.  Nothing of a keypoint leaves its wave between the two steps: no oriented
-// list, no launch boundary (the orientation launch of the headline frame's octave 0 lasted 57 us for 25 us worth of
-// instructions -- a launch of short latency chains ends with its slowest wave -- and mark_group_kernel plus two dispatch
-// gaps followed it), no freezing of list ranges between the groups.  The orientation scratch lives in the value pool of the
-// descriptor's routing tables, which is free between two descriptors; the angles wait in its unused words [900, 936).
-template <bool MAPS>
-__device__ __forceinline__ void fused_waves(const OctaveTable &tab, float ori_sigma, const float4 *__restrict__ kp,
-                                            const int *__restrict__ kp_aux, int n, Counters *cnt, int group, int out_capacity,
-                                            KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
-                                            DescRowLds *lds_all, double *fold, int *next, int nblocks) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    DescRowLds &L = lds_all[wave];
-    siftmath::load_atan_fold(fold);
-    desc_pool_init(L.P, lane);
-    __syncthreads();                     // the only workgroup barrier: the fold table
-    const int gwave = blockIdx.x * 4 + wave, nwaves = nblocks * 4;
-    const DescRoute rt = desc_route_of(L.P, lane);
-    const float4 *pool4 = reinterpret_cast<const float4 *>(L.P.pool);
-    OriWaveScratch &O = *reinterpret_cast<OriWaveScratch *>(L.P.pool);
-    static_assert(sizeof(OriWaveScratch) <= 896 * sizeof(float), "orientation scratch inside the value area of the pool");
-    float *peaks = &L.P.pool[900];
-
-    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-    auto advance = [&](int i) {
-        if (!next) return i + nwaves;
-        int t = 0;
-        if (lane == 0) t = atomicAdd(next, 1);
-        return nwaves + __builtin_amdgcn_readfirstlane(t);
-    };
-    int made = 0;
-    for (int t = gwave; t < n; t = advance(t)) {
-        float4 k = kp[t];                // (peak, row, col, sigma)
-        k.x = uni(k.x); k.y = uni(k.y); k.z = uni(k.z); k.w = uni(k.w);
-        const int aux = __builtin_amdgcn_readfirstlane(kp_aux[t]);       // detection scale | octave << 8
-        if (!(k.y >= 0.0f)) continue;
-        float ox, oy, os;
-        const int np = __builtin_amdgcn_readfirstlane(orient_wave<MAPS>(tab, ori_sigma, k, aux, O, peaks, fold, lane, ox, oy, os));
-        if (np == 0) continue;
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&cnt->n_out, np);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        made += np;
-        ox = uni(ox); oy = uni(oy); os = uni(os);
-#pragma unroll 1
-        for (int q = 0; q < np; q++) {
-            const int i = slot + q;
-            if (i >= out_capacity) { if (lane == 0) cnt->overflow = 1; break; }
-            const float4 kq = make_float4(ox, oy, os, uni(peaks[q]));
-            KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
-            desc_one_wave<MAPS>(tab, kq, aux, records + i, hrec, L, fold, rt, pool4, lane PH_NONE);
-        }
-    }
-    if (lane == 0 && made) atomicAdd(&cnt->grp_made[group], made);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same descriptor, ONE WORKGROUP (four waves) per keypoint: for sparse groups.  With a wave per keypoint a launch
@@ -968,8 +774,7 @@ struct alignas(16) DescTeamLds {
 
 template <bool MAPS>
 __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
-                                                int start, int end, KpRecord *__restrict__ records, KpRecord *host_records,
-                                                int host_capacity, DescTeamLds &T, double *fold) {
+                                                int start, int end, const RecordSink *sink, DescTeamLds &T, double *fold) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     DescPool &P = T.w[wave];
     siftmath::load_atan_fold(fold);
@@ -984,11 +789,9 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
         kq.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.z)));
         kq.w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.w)));
         const int aux = __builtin_amdgcn_readfirstlane(oaux[i]);         // detection scale | octave << 8
-        KpRecord *rec = records + i;
-        KpRecord *hrec = (host_records && i < host_capacity) ? host_records + i : nullptr;
         if (!(kq.y >= 0.0f)) {           // hole of an oriented list (stage replay only)
             __syncthreads();             // the previous keypoint's record may still be leaving through T.V
-            if (wave == 0) store_record(rec, hrec, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(T.V));
+            if (wave == 0) store_record(sink, i, kq, 0, 0, lane, reinterpret_cast<unsigned char *>(T.V));
             continue;
         }
         DescWindow w;
@@ -1122,7 +925,7 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
         // (int)(512.0*v) in double, MIN(255, .), NaN -> 0 (see the oracle's note)
         if (tid < 128) T.Q[tid] = min(255, (acc == acc) ? (int)(512.0 * (double)acc) : 0);
         __syncthreads();                                              // T.Q complete, T.V free
-        if (wave == 0) store_record(rec, hrec, kq, T.Q[lane], T.Q[lane + 64], lane, reinterpret_cast<unsigned char *>(T.V));
+        if (wave == 0) store_record(sink, i, kq, T.Q[lane], T.Q[lane + 64], lane, reinterpret_cast<unsigned char *>(T.V));
         // the next keypoint's first barrier (1b) orders this store_record before anything rewrites T.V / T.Q
     }
 }
@@ -1138,15 +941,20 @@ union DescLds {
 
 template <bool MAPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
-void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, const Counters *cnt,
+void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
-                       int out_capacity, KpRecord *__restrict__ records, KpRecord *host_records, int host_capacity,
-                       int team_below, int dynamic, int dense_blocks, int small_blocks, const int *__restrict__ order) {
+                       int out_capacity, KpRecord *__restrict__ records, int rec_capacity, KpRecord *host_records, int host_capacity,
+                       int team_below, int dynamic, int dense_blocks, int small_blocks, const int *__restrict__ ord, int bucket_below) {
     __shared__ DescLds lds;
     __shared__ double fold[36];
+    __shared__ RecordSink sink;
     int start = range_start, end = range_end;
-    if (cnt) { start = cnt->grp_out_start[group]; end = min(cnt->grp_out_end[group], out_capacity); }
-    if (end - start < team_below) descriptor_team<MAPS>(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.team, fold);
+    if (cnt) { start = 0; end = min(cnt->g_out[group], out_capacity); }
+    // scale 3 first (the hand-out lists) for groups below `bucket_below` keypoints whose lists are complete; list order otherwise
+    const bool bucketed = cnt && ord && end - start >= team_below && end - start < bucket_below && cnt->g_out[group] <= out_capacity &&
+                          cnt->g_ord[group][0] + cnt->g_ord[group][1] + cnt->g_ord[group][2] == end;
+    descriptor_open(cnt, group, end, records, rec_capacity, host_records, host_capacity, bucketed ? ord : nullptr, out_capacity, &sink);   // (before any workgroup leaves)
+    if (end - start < team_below) descriptor_team<MAPS>(tab, okp, oaux, start, end, &sink, lds.team, fold);
     else {
         // three workgroups per CU instead of four on a dense group: 154 k keypoints 5.56 -> 5.45 ms per call (the 9 k
         // keypoints of the headline frame prefer the full set: 0.903 against 0.927 ms)
@@ -1156,30 +964,8 @@ void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const in
         const int count = end - start;
         const int nblocks = count >= 65536 ? min((int)gridDim.x, dense_blocks) : (count < 16384 ? min((int)gridDim.x, small_blocks) : (int)gridDim.x);
         if ((int)blockIdx.x >= nblocks) return;
-        descriptor_waves<MAPS>(tab, okp, oaux, start, end, records, host_records, host_capacity, lds.rows, fold,
-                         (cnt && dynamic) ? const_cast<int *>(&cnt->desc_next[group]) : nullptr, nblocks,
-                         (cnt && order && cnt->grp_sorted[group]) ? order : nullptr);
+        descriptor_waves<MAPS>(tab, okp, oaux, start, end, &sink, lds.rows, fold, (cnt && dynamic) ? &cnt->desc_next[group] : nullptr, nblocks);
     }
 }
-
-#ifdef SIFT_DEV_VARIANTS
-// kp / kp_aux: the GROUP's own refined list (cnt->kp_count[group] entries): with one list per group nothing has to be
-// frozen before the other chain appends.
-template <bool MAPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_WAVES, 8)))
-void keypoint_fused_kernel(OctaveTable tab, float ori_sigma, const float4 *__restrict__ kp, const int *__restrict__ kp_aux,
-                           Counters *cnt, int group, int kp_capacity, int out_capacity, KpRecord *__restrict__ records,
-                           KpRecord *host_records, int host_capacity, int dynamic, int dense_blocks, int small_blocks) {
-    __shared__ DescLds lds;
-    __shared__ double fold[36];
-    const int n_all = cnt->kp_count[group];
-    const int n = min(n_all, kp_capacity);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n_all > kp_capacity) cnt->overflow = 1;
-    const int nblocks = n >= 65536 ? min((int)gridDim.x, dense_blocks) : (n < 16384 ? min((int)gridDim.x, small_blocks) : (int)gridDim.x);
-    if ((int)blockIdx.x >= nblocks) return;
-    fused_waves<MAPS>(tab, ori_sigma, kp, kp_aux, n, cnt, group, out_capacity, records, host_records, host_capacity, lds.rows, fold,
-                      dynamic ? &cnt->desc_next[group] : nullptr, nblocks);
-}
-#endif
 
 }  // namespace siftk

@@ -337,8 +337,9 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ i
 // ------------------------------------------------------------------------------------------
 // Fused separable blur, "marching" form, for large planes.
 //
-// A 128-thread workgroup (2 waves) owns a strip 256 columns wide and marches down `nblocks`
-// blocks of N rows:
+// (Round 1's one-block form -- a 128-thread workgroup doing both passes -- is in the history, commit 55027f7: blur_march_kernel;
+// what follows describes the arithmetic both forms share, the team form below is the one the product launches.)
+// A workgroup owns a strip 256 columns wide and marches down `nblocks` blocks of N rows:
 //   * the next block's N x (256+N-1) inputs are prefetched into registers while the current block
 //     is processed, then staged in LDS with the rows interleaved in pairs ([row pair][col][row&1]),
 //   * horizontal pass in place in LDS: a lane owns 4 consecutive outputs of a ROW PAIR and slides
@@ -359,201 +360,6 @@ __global__ __launch_bounds__(256) void blur_hv_kernel(const void *__restrict__ i
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int N, int NT = 128> struct MarchGeom {
-    static constexpr int TX = 2 * NT;                        // 2 columns per thread
-    static constexpr int C = (N & 1) ? N / 2 : N / 2 - 1;
-    static constexpr int NP = (N + 1) / 2;                   // row pairs per block
-    static constexpr int COLS = TX + N - 1;
-    static constexpr int PITCH = (COLS + 3) & ~3;            // columns per row pair
-    static constexpr int NW = (N + 3 + 1) & ~1;              // columns read per 4-output H task (even)
-    static constexpr int LDS_BYTES = NP * PITCH * 2 * 4;
-    static constexpr int HALO = N - 1;                       // columns beyond the first 256
-    static constexpr int NB = (NP * HALO + NT - 1) / NT;      // halo pair-elements per thread
-};
-
-template <int N, bool NORM, int NT, int DT = 0>
-__global__ __launch_bounds__(NT) void blur_march_kernel(const void *__restrict__ in, float *__restrict__ out,
-                                                        int W, int H, int nblocks, TapsArg<N> taps,
-                                                        const uint32_t *__restrict__ mm) {
-    using G = MarchGeom<N, NT>;
-    static_assert(N & 1, "marching blur needs an odd tap count");
-    extern __shared__ float4 smem4[];
-    float *s = reinterpret_cast<float *>(smem4);
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * G::TX;
-    const int rows_out = nblocks * N - (N - 1);
-    const int ys = blockIdx.y * rows_out;            // first output row of this segment
-    const int yend = min(ys + rows_out, H);
-    float mn = 0.f, range = 1.f;
-    if (NORM) { mn = ord2f(mm[0]); range = ord2f(mm[1]) - mn; }
-
-    // staging duty of this thread: columns tid and tid+NT of every row, plus NB halo pair-elements
-    const int gx_a = reflect_index(x0 - G::C + tid, W);
-    const int gx_b = reflect_index(x0 - G::C + NT + tid, W);
-    int hb_rp[G::NB], hb_col[G::NB], hb_gx[G::NB];
-#pragma unroll
-    for (int u = 0; u < G::NB; u++) {
-        const int e = tid + NT * u;
-        hb_rp[u] = (e < G::NP * G::HALO) ? e / G::HALO : -1;
-        hb_col[u] = G::TX + e % G::HALO;
-        hb_gx[u] = reflect_index(x0 - G::C + hb_col[u], W);
-    }
-
-    // 32-bit byte offsets from the (scalar) plane base keep each load's address in one VGPR
-    // (typed frames: the same offset / 4 is the pixel index handed to the converter)
-    auto ld = [&](unsigned byte_off) {
-        if constexpr (DT == 0) return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + byte_off);
-        else return load_px<DT>(in, (size_t)(byte_off >> 2));
-    };
-    const unsigned W4 = (unsigned)W * 4u;
-    auto norm2 = [&](f32x2 v) {
-        if (NORM) { v.x = 255.0f * (v.x - mn) / range; v.y = 255.0f * (v.y - mn) / range; }   // preprocess.cl:250
-        return v;
-    };
-
-    f32x2 acc[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) acc[k] = (f32x2){0.f, 0.f};
-    const int gxo = x0 + 2 * tid;                     // first of the two output columns
-    const bool vec_store = ((W & 1) == 0) && (gxo + 1 < W);
-
-    // register look-ahead: the next block's inputs are fetched while the current block is filtered
-    f32x2 pa[G::NP], pb[G::NP], ph[G::NB];
-    auto prefetch = [&](int blk) {
-        const int v0 = ys - G::C + blk * N;
-        if (BLUR_ABL & 4) {
-#pragma unroll
-            for (int rp = 0; rp < G::NP; rp++) { pa[rp] = (f32x2){1.f, 2.f}; pb[rp] = (f32x2){3.f, 4.f}; }
-#pragma unroll
-            for (int u = 0; u < G::NB; u++) ph[u] = (f32x2){5.f, 6.f};
-            return;
-        }
-        if (v0 >= 0 && v0 + N + 1 <= H) {             // interior rows: walk per-thread offsets
-            unsigned oa = ((unsigned)v0 * (unsigned)W + (unsigned)gx_a) * 4u;
-            unsigned ob = ((unsigned)v0 * (unsigned)W + (unsigned)gx_b) * 4u;
-#pragma unroll
-            for (int rp = 0; rp < G::NP; rp++) {
-                pa[rp].x = ld(oa); pa[rp].y = ld(oa + W4);
-                pb[rp].x = ld(ob); pb[rp].y = ld(ob + W4);
-                oa += 2u * W4; ob += 2u * W4;
-            }
-        } else {
-#pragma unroll
-            for (int rp = 0; rp < G::NP; rp++) {
-                const unsigned r0 = (unsigned)reflect_index(v0 + 2 * rp, H) * W4, r1 = (unsigned)reflect_index(v0 + 2 * rp + 1, H) * W4;
-                pa[rp].x = ld(r0 + 4u * gx_a); pa[rp].y = ld(r1 + 4u * gx_a);
-                pb[rp].x = ld(r0 + 4u * gx_b); pb[rp].y = ld(r1 + 4u * gx_b);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < G::NB; u++) {
-            ph[u] = (f32x2){0.f, 0.f};
-            if (hb_rp[u] >= 0) {
-                ph[u].x = ld((unsigned)reflect_index(v0 + 2 * hb_rp[u], H) * W4 + 4u * hb_gx[u]);
-                ph[u].y = ld((unsigned)reflect_index(v0 + 2 * hb_rp[u] + 1, H) * W4 + 4u * hb_gx[u]);
-            }
-        }
-    };
-    prefetch(0);
-
-    for (int blk = 0; blk < nblocks; blk++) {
-        __syncthreads();                              // previous block's vertical reads are done
-        // ---- stage the prefetched rows as [row pair][column][row & 1]
-#pragma unroll
-        for (int rp = 0; rp < G::NP; rp++) {
-            *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + tid) * 2) = norm2(pa[rp]);
-            *reinterpret_cast<f32x2 *>(s + (rp * G::PITCH + NT + tid) * 2) = norm2(pb[rp]);
-        }
-#pragma unroll
-        for (int u = 0; u < G::NB; u++)
-            if (hb_rp[u] >= 0) *reinterpret_cast<f32x2 *>(s + (hb_rp[u] * G::PITCH + hb_col[u]) * 2) = norm2(ph[u]);
-        __syncthreads();
-        if (blk + 1 < nblocks) prefetch(blk + 1);
-        // ---- horizontal pass in place: a task = 4 consecutive columns of one row pair; the NT/2 tasks of a
-        //      row pair are consecutive lanes of one wave (a whole wave for NT = 128, half a wave for NT = 64)
-        for (int task = tid; task < ((BLUR_ABL & 1) ? 0 : G::NP * (NT / 2)); task += NT) {
-            const int rp = task / (NT / 2), t4 = task % (NT / 2);
-            float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
-            // sliding window streamed through registers: b128 loads run PRE ahead of their first use
-            f32x2 w[G::NW];
-            constexpr int PRE = 4;
-#pragma unroll
-            for (int k = 0; k < PRE && k < G::NW / 2; k++) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
-                w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
-            }
-            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < N; q++) {
-                if ((q & 1) == 0) {
-                    const int k = q / 2 + PRE;
-                    if (k < G::NW / 2) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
-                        w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const float tp = taps.t[N - 1 - q];
-                const f32x2 tp2 = {tp, tp};
-                a0 = a0 + w[q] * tp2;
-                a1 = a1 + w[q + 1] * tp2;
-                a2 = a2 + w[q + 2] * tp2;
-                a3 = a3 + w[q + 3] * tp2;
-            }
-            __builtin_amdgcn_wave_barrier();          // the whole row pair lives in this wave: reads precede stores
-            // result layout for the vertical pass: [row pair][column pair][row & 1][column & 1]
-            *reinterpret_cast<f32x4 *>(rowp) = (f32x4){a0.x, a1.x, a0.y, a1.y};
-            *reinterpret_cast<f32x4 *>(rowp + 4) = (f32x4){a2.x, a3.x, a2.y, a3.y};
-        }
-        __syncthreads();
-        // ---- vertical march over the N rows of this block (fully unrolled: static accumulator slots)
-        const int ybase = ys + blk * N - (N - 1);     // output row completed by step kk is ybase + kk
-        float *optr = out + ((ptrdiff_t)ybase * W + gxo);   // only dereferenced for valid rows
-        f32x4 hv_next = *reinterpret_cast<const f32x4 *>(s + (2 * tid) * 2);
-#pragma unroll
-        for (int rp = 0; rp < G::NP; rp++) {
-            const f32x4 hv = hv_next;                 // LDS read issued one row pair ahead
-            if (rp + 1 < G::NP) hv_next = *reinterpret_cast<const f32x4 *>(s + ((rp + 1) * G::PITCH + 2 * tid) * 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int kk = 2 * rp + half;
-                if (kk < N) {
-                    const f32x2 h = half ? hv.zw : hv.xy;
-                    // taps[N-1-j] == taps[j] bitwise: product k feeds the two outputs whose tap index is k or N-1-k.
-                    // Each accumulator receives exactly one addition per input row, so the order of the additions
-                    // within a row is free; forming a product and retiring it at once keeps one product live, not (N+1)/2.
-#pragma unroll
-                    for (int k = 0; k < ((BLUR_ABL & 2) ? 1 : (N + 1) / 2); k++) {
-                        const f32x2 t2 = {taps.t[k], taps.t[k]};
-                        const f32x2 prod = h * t2;
-                        const int slot_a = (kk - k + N) % N;             // tap index j = k
-                        const int slot_b = (kk - (N - 1 - k) + N) % N;   // tap index j = N-1-k
-                        if (k == 0) acc[slot_a] = (f32x2){0.f, 0.f} + prod;
-                        else acc[slot_a] = acc[slot_a] + prod;
-                        // Pin the additions here: otherwise the compiler sinks each output's whole
-                        // add chain into its (conditional) store and keeps every product alive.
-                        asm volatile("" : "+v"(acc[slot_a]));
-                        if (k != N - 1 - k) {
-                            acc[slot_b] = acc[slot_b] + prod;
-                            asm volatile("" : "+v"(acc[slot_b]));
-                        }
-                    }
-                    const int done = (kk + 1) % N;    // the output whose last tap (j = N-1) was just added
-                    const int y = ybase + kk;
-                    if (y >= ys && y < yend && !((BLUR_ABL & 8) && acc[done].x != 12345.678f)) {
-                        if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];
-                        else {
-                            if (gxo < W) optr[0] = acc[done].x;
-                            if (gxo + 1 < W) optr[1] = acc[done].y;
-                        }
-                    }
-                    optr += W;
-                }
-            }
-        }
-    }
-}
 
 template <int N, int S> struct SubSplit {
     static constexpr int RB = (((N + S - 1) / S) + 1) & ~1;
@@ -578,7 +384,7 @@ template <int N, int NT, int S> struct March2Geom {
 
 
 // ------------------------------------------------------------------------------------------
-// Marching blur, team form (used for >= 15 taps on large planes; bit-identical to blur_march_kernel).
+// Marching blur, team form (used for >= 15 taps on large planes; bit-identical to the one-block form of round 1).
 // The N rows of one accumulator period are staged and filtered in S sub-blocks of RB rows (SubSplit), and the two
 // passes run on different waves of the workgroup:
 // One workgroup = 256 threads = an H team (waves 0-1) and a V team (waves 2-3) on one 256-column strip.
@@ -819,217 +625,6 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
 #undef VPASS
 }
 
-#ifdef SIFT_DEV_VARIANTS
-// ------------------------------------------------------------------------------------------
-// DEVELOPMENT BUILDS ONLY (SIFT_DEV_VARIANTS; option "glds").  Measured on a 4096^2 plane, bit-identical to blur_team_kernel:
-// 37.6 / 42.7 / 44.0 / 50.0 / 64.6 us against 36.6 / 40.5 / 41.9 / 48.5 / 62.0 for 11 / 15 / 17 / 21 / 27 taps, whole call 0.806 against 0.793 ms
-// -- the staging it removes was the V team's, and the H team bounds a step; the registers it frees (11 taps: 96 -> 59 VGPRs, 15:
-// 124 -> 74) cannot be turned into occupancy because more, shorter segments cost more warm-up rows than the extra waves hide
-// (1280 / 1536 / 2048 workgroups: slower for every tap count).  With the runs issued by the H team: +13 %.
-// Marching blur, team form with LDS-DMA staging (round 4; plain f32 planes without normalisation: every launch of a large
-// octave but the initial one).  Same strips, segments, sub-blocks, H pass and V march as blur_team_kernel -- the same
-// arithmetic in the same order, bit-identical -- but the rows of a sub-block go from HBM straight into their LDS buffer:
-//   * `global_load_lds_dword`: the LDS destination of a wave-wide load is base + 4 * lane, the source address is per lane, so
-//     lane l of run j of row pair rp fetches (row 2 rp + (l & 1), column 32 j + (l >> 1)): one instruction fills 32 columns of
-//     the [row pair][column][row & 1] image the packed H pass reads -- no look-ahead registers, no ds_write pass, no staging
-//     VALU work, and the V team (whose 27 packed accumulators set the kernel's register count) stages nothing at all;
-//   * the V team issues the runs (the H team, 2N packed operations per row pair against 1.5N, is the one without time to spare:
-//     with the runs on the H team every launch was 13 % slower): after marching sub-block g - 1 it waits for the runs of g + 1,
-//     issued one step earlier, and issues those of g + 2 -- into a ring of FOUR buffers, because the H team may still be
-//     filtering g in the buffer next to it and a ring of three would hand out the one being marched;
-//   * barriers are raw `s_barrier` behind `s_waitcnt lgkmcnt(0)`: a __syncthreads() would also wait for the runs in flight.
-typedef __attribute__((address_space(3))) void blur_lds_void;
-typedef __attribute__((address_space(1))) const void blur_glb_void;
-__device__ __forceinline__ void blur_team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int N, int S, int HW = 2>
-__global__ __launch_bounds__(64 * HW + 128) void blur_glds_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                          int W, int H, int nblocks, int last_subs, int rows_out,
-                                                          TapsArg<N> taps, float *__restrict__ next0) {
-    constexpr int NT = 128;                       // threads of the V team (2 columns each)
-    using G = March2Geom<N, NT, S>;
-    using SS = SubSplit<N, S>;
-    static_assert(N & 1, "marching blur needs an odd tap count");
-    constexpr int BUF = G::NPS * G::PITCH * 2;    // floats per LDS buffer
-    constexpr int NBUF = 4;
-    constexpr int JN = (G::COLS + 31) / 32;       // runs of 32 columns per row pair
-    extern __shared__ float4 smem4[];
-    float *sbase = reinterpret_cast<float *>(smem4);
-    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 64 * HW ? 1 : 0;
-    const int tid = role ? (int)threadIdx.x - 64 * HW : (int)threadIdx.x;
-    const int x0 = blockIdx.x * G::TX;
-    const int ys = blockIdx.y * rows_out;
-    const int yend = min(ys + rows_out, H);
-    const unsigned W4 = (unsigned)W * 4u;
-    auto exists = [&](int blk, int sub) { return blk < nblocks - 1 || (blk == nblocks - 1 && sub < last_subs); };
-
-    if (role == 0) {
-        // ================= H team: horizontal pass
-        auto hpass = [&](float *s, int np) {
-            for (int task = tid; task < np * (NT / 2); task += 64 * HW) {
-                const int rp = task / (NT / 2), t4 = task % (NT / 2);
-                float *rowp = s + (rp * G::PITCH + 4 * t4) * 2;
-                f32x2 w[G::NW];
-                constexpr int PRE = 4;
-#pragma unroll
-                for (int k = 0; k < PRE && k < G::NW / 2; k++) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
-                    w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
-                }
-                f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < N; q++) {
-                    if ((q & 1) == 0) {
-                        const int k = q / 2 + PRE;
-                        if (k < G::NW / 2) {
-                            const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + 4 * k);
-                            w[2 * k] = v.xy; w[2 * k + 1] = v.zw;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    const float tp = taps.t[N - 1 - q];
-                    const f32x2 tp2 = {tp, tp};
-                    a0 = a0 + w[q] * tp2;
-                    a1 = a1 + w[q + 1] * tp2;
-                    a2 = a2 + w[q + 2] * tp2;
-                    a3 = a3 + w[q + 3] * tp2;
-                }
-                __builtin_amdgcn_wave_barrier();
-                *reinterpret_cast<f32x4 *>(rowp) = (f32x4){a0.x, a1.x, a0.y, a1.y};
-                *reinterpret_cast<f32x4 *>(rowp + 4) = (f32x4){a2.x, a3.x, a2.y, a3.y};
-            }
-        };
-        blur_team_barrier();                       // (the V team's prologue: sub-block 0 has landed)
-        int g = 0;
-        for (int blk = 0; blk < nblocks; blk++) {
-#pragma unroll
-            for (int sub = 0; sub < S; sub++) {
-                if (blk == nblocks - 1 && sub >= last_subs) break;      // workgroup uniform
-                hpass(sbase + (g % NBUF) * BUF, SS::pairs(sub));
-                blur_team_barrier();
-                g++;
-            }
-        }
-        return;
-    }
-
-    // ================= V team: vertical march, global stores
-    f32x2 acc[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) acc[k] = (f32x2){0.f, 0.f};
-    const int gxo = x0 + 2 * tid;
-    const bool vec_store = ((W & 1) == 0) && (gxo + 1 < W);
-    const int lane = tid & 63;
-    const int hw = __builtin_amdgcn_readfirstlane(tid >> 6);     // the two V waves share the runs (a scalar: the split is a scalar branch)
-    const unsigned lds0 = (unsigned)(uintptr_t)sbase;           // LDS byte address of the ring (low half of the generic address)
-    unsigned colb[JN];                        // byte offset of this lane's column in run j (reflected at the plane's edges)
-    bool colv[JN];                            // the run's tail beyond the strip's last halo column is not loaded
-#pragma unroll
-    for (int j = 0; j < JN; j++) {
-        const int col = 32 * j + (lane >> 1);
-        colv[j] = col < G::COLS;
-        colb[j] = 4u * (unsigned)reflect_index(x0 - G::C + min(col, G::COLS - 1), W);
-    }
-    // one straight-line copy of the runs per V wave (HWC = the wave: a branch per run costs more than the run)
-    auto issue_wave = [&](auto HWC, int blk, int sub, int buf) {
-        constexpr int hwc = decltype(HWC)::value;
-        const int np = SS::pairs(sub);        // (sub is a compile-time value at every call)
-        const int v0 = ys - G::C + blk * N + sub * SS::RB;
-#pragma unroll
-        for (int rp = 0; rp < G::NPS; rp++) {
-            if (rp < np) {
-                const unsigned r0 = (unsigned)reflect_index(v0 + 2 * rp, H) * W4, r1 = (unsigned)reflect_index(v0 + 2 * rp + 1, H) * W4;
-                const unsigned rowb = (lane & 1) ? r1 : r0;
-#pragma unroll
-                for (int j = 0; j < JN; j++) {
-                    if ((rp * JN + j) % 2 == hwc) {
-                        // (the LDS address as an integer: a cast of the generic pointer costs a null test per run)
-                        const unsigned dst = lds0 + 4u * (unsigned)(buf * BUF + (rp * G::PITCH + 32 * j) * 2);
-                        if (32 * j + 32 <= G::COLS || colv[j])            // only the last run has lanes beyond the strip's halo
-                            __builtin_amdgcn_global_load_lds((blur_glb_void *)(reinterpret_cast<const char *>(in) + (rowb + colb[j])),
-                                                             reinterpret_cast<blur_lds_void *>((uintptr_t)dst), 4, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-    auto issue = [&](int blk, int sub, int buf) {
-        if (hw == 0) issue_wave(std::integral_constant<int, 0>{}, blk, sub, buf);
-        else issue_wave(std::integral_constant<int, 1>{}, blk, sub, buf);
-    };
-#define VPASS(sbuf, blk_, sub_)                                                                              \
-    {                                                                                                        \
-        const int np_ = SS::pairs(sub_), nrows_ = SS::rows(sub_);                                            \
-        const int ybase_ = ys + (blk_) * N - (N - 1);                                                        \
-        float *optr = out + ((ptrdiff_t)(ybase_ + (sub_) * SS::RB) * W + gxo);                              \
-        f32x4 hv_next = *reinterpret_cast<const f32x4 *>((sbuf) + (2 * tid) * 2);                           \
-        _Pragma("unroll") for (int rp = 0; rp < G::NPS; rp++) {                                              \
-            if (rp < np_) {                                                                                  \
-                const f32x4 hv = hv_next;                                                                    \
-                if (rp + 1 < np_) hv_next = *reinterpret_cast<const f32x4 *>((sbuf) + ((rp + 1) * G::PITCH + 2 * tid) * 2); \
-                __builtin_amdgcn_sched_barrier(0);                                                           \
-                _Pragma("unroll") for (int half = 0; half < 2; half++) {                                     \
-                    if (2 * rp + half < nrows_) {                                                            \
-                        const int kk = (sub_) * SS::RB + 2 * rp + half;                                      \
-                        const f32x2 h = half ? hv.zw : hv.xy;                                                \
-                        _Pragma("unroll") for (int k = 0; k < (N + 1) / 2; k++) {                            \
-                            const f32x2 t2 = {taps.t[k], taps.t[k]};                                         \
-                            const f32x2 prod = h * t2;                                                       \
-                            const int slot_a = (kk - k + N) % N, slot_b = (kk - (N - 1 - k) + N) % N;        \
-                            if (k == 0) acc[slot_a] = (f32x2){0.f, 0.f} + prod;                              \
-                            else acc[slot_a] = acc[slot_a] + prod;                                           \
-                            asm volatile("" : "+v"(acc[slot_a]));                                            \
-                            if (k != N - 1 - k) { acc[slot_b] = acc[slot_b] + prod; asm volatile("" : "+v"(acc[slot_b])); } \
-                        }                                                                                    \
-                        const int done = (kk + 1) % N;                                                       \
-                        const int y = ybase_ + kk;                                                           \
-                        if (y >= ys && y < yend) {                                                           \
-                            if (vec_store) *reinterpret_cast<f32x2 *>(optr) = acc[done];                     \
-                            else { if (gxo < W) optr[0] = acc[done].x; if (gxo + 1 < W) optr[1] = acc[done].y; } \
-                            if (next0 && !(y & 1) && (y >> 1) < (H >> 1) && (gxo >> 1) < (W >> 1))           \
-                                next0[(size_t)(y >> 1) * (W >> 1) + (gxo >> 1)] = acc[done].x;              \
-                        }                                                                                    \
-                        optr += W;                                                                           \
-                    }                                                                                        \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-    // prologue: sub-block 0 lands, sub-block 1 is in flight
-    issue(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (S > 1) { if (exists(0, 1 % S)) issue(0, 1 % S, 1); }
-    else if (exists(1, 0)) issue(1, 0, 1);
-    blur_team_barrier();
-    int g = 0;
-    for (int blk = 0; blk < nblocks; blk++) {
-#pragma unroll
-        for (int sub = 0; sub < S; sub++) {
-            if (blk == nblocks - 1 && sub >= last_subs) break;      // workgroup uniform
-            if (g > 0) {
-                float *prev = sbase + ((g + NBUF - 1) % NBUF) * BUF;
-                if (sub == 0) { VPASS(prev, blk - 1, S - 1) } else { VPASS(prev, blk, (sub + S - 1) % S) }
-            }
-            // the runs of step g + 1, issued a step ago, have landed (the wait also covers this step's stores: the V team is
-            // the one with time to spare); then those of step g + 2 go out
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int sub2 = (sub + 2) % S, blk2 = blk + (sub + 2) / S;
-            if (exists(blk2, sub2)) issue(blk2, sub2, (g + 2) % NBUF);
-            blur_team_barrier();
-            g++;
-        }
-    }
-    {
-        float *prev = sbase + ((g + NBUF - 1) % NBUF) * BUF;
-        if (last_subs >= S) { VPASS(prev, nblocks - 1, S - 1) }
-        if constexpr (S > 1) { if (last_subs == 1) { VPASS(prev, nblocks - 1, 0) } }
-        if constexpr (S > 2) { if (last_subs == 2) { VPASS(prev, nblocks - 1, 1) } }
-        if constexpr (S > 3) { if (last_subs == 3) { VPASS(prev, nblocks - 1, 2) } }
-    }
-#undef VPASS
-}
-
-#endif  // SIFT_DEV_VARIANTS
 
 // Generic (any tap count, incl. even sizes) two-pass blur: plain global loads, used only for
 // non-default init_sigma schedules and stage replay.  Same arithmetic.

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(SIFT_TAIL_THREADS) __attribute__((amdgpu_waves_per_
                                                                        int *__restrict__ n_cand, int *__restrict__ ready,
                                                                        float4 *__restrict__ kp,
                                                                        int *__restrict__ kp_aux, int *__restrict__ n_kp, int kp_capacity,
-                                                                       int *__restrict__ overflow, int *__restrict__ timed_out) {
+                                                                       int *__restrict__ c_scale_all, int *__restrict__ timed_out) {
     extern __shared__ float4 tail_smem4[];
     float *smem = reinterpret_cast<float *>(tail_smem4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(SIFT_TAIL_THREADS) __attribute__((amdgpu_waves_per_
     __syncthreads();
     // ---- refinement of the candidates
     const int found = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0 && found > cand_capacity && overflow) *overflow = 1;
+    // (cand_capacity is three candidates per sample of the largest tail plane: the list cannot be cut)
     refine_candidates(b, W, H, cand, min(found, cand_capacity), peak_thresh, init_sigma, kp, kp_aux, n_kp, kp_capacity,
-                      o.oct, tid, SIFT_TAIL_THREADS);
+                      o.oct, tid, SIFT_TAIL_THREADS, c_scale_all ? c_scale_all + 3 * o.oct : nullptr);
 }
 
 }  // namespace siftk

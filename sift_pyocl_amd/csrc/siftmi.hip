@@ -44,6 +44,7 @@ thread_local std::string g_err;
 #define SIFT_SYNC_EVENT (hipEventDisableTiming | hipEventDisableSystemFence)
 #endif
 #define SIFTMI_ETAILRETRY (-100)   // internal: plan_wait -> siftmi_plan_keypoints, never returned through the C ABI
+#define SIFTMI_EGROW (-101)        // internal, likewise: a list was grown, the image has to run again
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -100,10 +101,7 @@ struct Options {
     int fused_convert = 1;   // typed frames converted at the point of use (0: separate convert pass)
     int overlap = 1;         // detection / description streams beside the pyramid stream (0: one stream)
     int march = 1;           // marching blur for large planes (0: tiled blur everywhere)
-    int team = 1;            // team form of the marching blur (0: one-block form)
-    int march_nt = 128;      // threads per workgroup of the one-block form (64 or 128)
     int march_wgs = 0;       // workgroups wanted by the marching blur (0: 1024, 768 for 27 taps)
-    int march_nb = 0;        // blocks per segment of the one-block form (0: derived)
     int ori_blocks = 4096, ori_pad = 0;      // orientation launch: workgroups (upper bound; the kernel cuts it down by the group's count)
     // descriptor launch: workgroups (keypoints are handed out dynamically, so a workgroup stays until the group is done:
     // 1024 = every wave slot of the chip, which starves the other stream's kernels for the whole launch -- 1024^2 smooth
@@ -125,18 +123,14 @@ struct Options {
     int desc_team = 2048;    // groups with fewer oriented keypoints than this are described by the workgroup-per-keypoint form (0: never); measured cross-over
                              // 1000-1800 alone (one workgroup slot per keypoint: 4 per CU); in a frame, round 4 (interleaved A/B, 1024 / 2048 / 3072 / 4096):
                              // 1024^2 smoothed 0.588 / 0.568 / 0.568 / 0.570 ms, 2048^2 white 0.500 / 0.499 / 0.520 / 0.521, headline and the other frames equal
-    int desc_sort = 0;       // groups of at most this many oriented keypoints (<= 16384) are described largest window first (0: list order).
-                             // Round 3 (16384): headline 0.818 -> 0.809 ms; round 4, after the descriptor kernel's per-keypoint set-up was
-                             // cut: list order 0.802-0.809 against 0.811-0.815 ordered (three interleaved A/B runs; 9 octaves 0.961 / 0.969,
-                             // 2048^2 equal) -- the later octaves' chain ends the frame, the order only shortens the other one, and the
-                             // counting sort sits on the critical path; neighbours in the list share their window pixels in the caches
-    int desc_sort_density = 600;   // ... and only with fewer keypoints than one per this many pixels of octave 0
+    int desc_bucket = 1 << 30;   // groups of fewer oriented keypoints than this are handed out scale 3 first in the wave form of the
+                             // descriptor launch (the three hand-out lists the orientation launch fills; 0: list order) -- see k_descriptor.hpp
+    int split0 = 0;          // octave 0 of a large frame in two groups: detection scale 1 (planes 0-3) is detected, oriented and described on
+                             // `stream2` from the moment plane 3 exists, under the last two blurs of the octave; scales 2-3 follow on `stream`
     int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
     int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)
     int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
     int desc_dynamic = 1;    // wave-per-keypoint form: keypoints beyond each wave's first are handed out through a device counter
-    int split_detect = 0;    // later octaves: detection on its own stream, off the chain of pyramids (interleaved A/B: 512^2 -3 %, 2048^2 / 4096^2 +-1 %, two pipelined 4096^2 lanes +10 %: off)
-    int early_pyr = 0;       // enqueue octave 1's pyramid before octave 0's detection / description (A/B: no gain anywhere, 512^2 +2 %)
     int tail_pixels = SIFT_TAIL_MAX_PIXELS;   // largest plane (W * H) the tail kernel takes
     int tail = 1;            // small octaves (<= 64 x 64) in one launch (octave_tail_kernel)
     int ext_rows = 0;        // rows per extrema strip: 0 by plane size (extrema_strip_rows)
@@ -144,25 +138,9 @@ struct Options {
                              // strips on a 4096^2 plane): the march of a strip re-reads two halo rows, and many short strips are many
                              // ramp-ups; interleaved A/B, whole call: 4096^2 0.835 (12288) / 0.823 (4000) / 0.809 (2000) / 0.817 ms (1000),
                              // 2048^2 0.521 -> 0.511, 2048^2 smoothed 1.544 -> 1.517, small frames unchanged; the launch alone 94 -> 81-86 us
-    int tile = 0;            // tile blur shape: 0 by plane size, 1 128x64, 2 64x32, 3 32x16
-    int chain0 = 1;          // octave 0 end to end on the pyramid stream, later octaves' pyramids on the second chain
-    int early_chain = 0;     // later octaves' chain starts when plane 3 of octave 0 exists (after its third blur), not after its fifth:
-                             // interleaved A/B 4096^2 0.854 -> 0.894 ms, 2048^2 0.523 -> 0.530 (octave 0's last two blurs slow down by more than the chain gains): off
-    int bands = 0;           // octave 0 of a large frame: detection -> orientation -> description pipelined over this many horizontal bands (<= 1: off).
-                             // Measured (headline frame, interleaved A/B): 0 bands 0.867 ms, 2: 0.962, 4: 1.028, 8: 1.348 -- a launch over a
-                             // quarter of the keypoints lasts as long as its slowest keypoint (~120 us with a wave per keypoint), the bands'
-                             // descriptor launches run one after the other, and the small detection / orientation launches each pay their
-                             // ramp: the serial phases are cheaper than the pipeline.  Kept for experiments, off.
     int ori_small_blocks = 608;   // orientation launch: workgroups used for a group of fewer than 16384 keypoints (512 until the descriptor launch was ordered: 0.809 ms; 576-640: 0.799-0.801; 704: 0.813)
     int spin = 1;            // poll the ending streams instead of a blocking wait
     int host_timing = 0;     // print the host time of plan_enqueue
-    int fused_kp = 0;        // development builds: orientation + description of a refined keypoint by one wave in ONE launch per group
-                             // (keypoint_fused_kernel), each group with its own refined list.  Bit-identical record sets; measured SLOWER:
-                             // headline 0.800 -> 0.952 ms, 2048^2 0.505 -> 0.627, 154 k keypoints 4.25 -> 4.76 -- the per-keypoint launches
-                             // are latency chains per wave (descriptor launch alone: 144 / 288 / 576 / 960 workgroups 775 / 438 / 288 / 242 us),
-                             // and the orientation of a keypoint (~13 us) lengthens the chain of the wave that then describes it (~69 us)
-                             // instead of running beside other keypoints' descriptors
-    int glds = 0;            // development builds: LDS-DMA staging in the team blur of large planes (blur_glds_kernel; measured 3-5 % slower)
     int tail_fault = 0;      // diagnostic: the next `tail_fault` images that go through octave_tail_kernel are treated as if a
                              // workgroup of it had timed out (exercises the host's re-run path; results do not change)
 };
@@ -181,6 +159,15 @@ size_t dtype_size(int dt) {
 
 }  // namespace
 
+// The lists of one group of octaves (k_keypoint.hpp: Counters): refined keypoints, oriented keypoints, the three
+// hand-out lists of the descriptor launch.  Capacities start at kpsize (plan.py:243) and grow on demand (grow_lists).
+struct GroupLists {
+    float4 *kp = nullptr;  int *kp_aux = nullptr;  int64_t cap_kp = 0;     // (peak, row, col, sigma), detection scale | octave << 8
+    float4 *okp = nullptr; int *oaux = nullptr;    int64_t cap_out = 0;    // (x, y, scale, angle), same tag
+    int *ord = nullptr;                                                     // 3 x cap_out
+    float4 *cand = nullptr; int64_t cap_cand = 0;                           // candidate list of the group's detection passes (one octave at a time)
+};
+
 struct siftmi_plan {
     void *chain = nullptr;        // open light-profile bracket (a Scope, profile == 1)
     int device = 0;
@@ -196,14 +183,11 @@ struct siftmi_plan {
     float *planes = nullptr;      // all octaves' blur planes: octave o, scale s at plane(o, s)
     std::vector<size_t> oct_off;  // float offset of octave o's first plane
     float *tmp = nullptr;         // generic blur only
-    hipStream_t stream2 = nullptr;            // detection / description of octave 0 (overlaps the next octaves' pyramid)
-    hipStream_t stream3 = nullptr;            // detection / description of the later octaves (overlaps group 0's descriptors)
-    hipStream_t stream4 = nullptr;            // banded octave 0: the descriptor launches of the bands (created on first use)
-    std::vector<hipEvent_t> ev_kp, ev_out;    // banded octave 0: band b refined (its range frozen) / band b oriented
-    int bands_last = 0;                       // bands of octave 0 in the image enqueued last (0: not banded)
+    hipStream_t stream2 = nullptr;            // scale 1 of a split octave 0 (detection to description); octave 0's gradient maps
+    hipStream_t stream3 = nullptr;            // the later octaves: pyramids, detection, description
     int64_t acc_calls = 0, acc_b0_launches = 0;   // running totals of the light profile (siftmi_plan_profile_totals)
     double acc_total_ms = 0, acc_b0_ms = 0, acc_b0_pixels = 0;
-    hipEvent_t ev_mark0 = nullptr, ev_grp1 = nullptr, ev_det = nullptr, ev_p3 = nullptr;
+    hipEvent_t ev_p3 = nullptr;               // plane 3 of octave 0 exists (split octave 0: stream2 starts there)
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
@@ -217,36 +201,29 @@ struct siftmi_plan {
     float *gmap = nullptr, *omap = nullptr;   // gradient maps (allocated on first use: half the size of `planes` each)
     size_t planes_floats = 0;
     bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves
-    int later_group = 1;                      // group index of the later octaves in that image
-    bool fused = false;                       // that image: one fused orientation + description launch per group, one refined list per group
-    // refined list (entries, detection scale | octave << 8, counter) the refinement of octave `oct` appends to
-    // (group 0 = octave 0 unless the tail kernel takes every octave; the later group's list lives in the oriented list's
-    // arrays, which a fused image does not use)
-    int tail_first_cur = 0;                   // first octave of that image's tail launch (n_oct: none)
-    int group_of(int oct) const { return (oct == 0 && tail_first_cur != 0) ? 0 : 1; }
-    float4 *kp_of(int oct) const { return (fused && group_of(oct)) ? okp : kp; }
-    int *kp_aux_of(int oct) const { return (fused && group_of(oct)) ? oaux : kp_scale; }
-    int *kp_counter_of(int oct) const { return fused ? &cnt->kp_count[group_of(oct)] : &cnt->n_kp; }
+    // the image being enqueued / waited for
+    bool split_cur = false;                   // octave 0 in two groups (0: scale 1, 1: scales 2-3)
+    unsigned groups_cur = 0;                  // bit g: group g has launches in this image
+    int tail_first_cur = 0;                   // first octave of the tail launch (n_oct: none)
     hipEvent_t ev_maps0 = nullptr;
     bool maps_unavailable = false;   // the lazy allocation of the gradient maps failed once: dense frames keep the lazy forms
     hipEvent_t ev_join = nullptr;
-    struct HostBack { Counters c, c2; } *hb = nullptr;   // pinned read-back blocks (one asynchronous D->H per ending stream)
-    hipStream_t wait_a = nullptr, wait_b = nullptr;      // the stream(s) the image enqueued last ends on
+    struct HostBack { Counters c[3]; } *hb = nullptr;    // pinned read-back blocks (one asynchronous D->H per ending stream)
+    hipStream_t wait_s[3] = {nullptr, nullptr, nullptr}; // the streams the image enqueued last ends on (hb->c[k] was copied on wait_s[k])
     void *warp_in = nullptr, *warp_out = nullptr;   // siftmi_plan_transform staging, grown on demand
     size_t warp_in_bytes = 0, warp_out_bytes = 0;
     hipEvent_t ev_wa = nullptr, ev_wb = nullptr;
     float *conv = nullptr;        // converted f32 input when dtype != f32
     uint32_t *mm = nullptr;
     Counters *cnt = nullptr;
-    float4 *cand = nullptr;
     float4 *tail_cand = nullptr;   // candidate lists of octave_tail_kernel: SIFT_TAIL_MAX_OCT x tail_cand_cap
     int tail_cand_cap = 0;
-    float4 *kp = nullptr;
-    int *kp_scale = nullptr;
-    float4 *okp = nullptr;
-    int *oaux = nullptr;
-    int *order = nullptr;         // hand-out order of the descriptor launch (mark_group_kernel), indices into okp
-    KpRecord *records = nullptr;
+    GroupLists grp[SIFT_GROUPS];
+    KpRecord *records = nullptr;  // the image's records: one block per group (descriptor_reserve)
+    int64_t cap_rec = 0;
+    bool in_flight = false;       // an image has been enqueued and not yet waited for (plan_wait) or drained
+    bool records_cut = false;     // the last image hit the reference's per-octave capacity and was cut to it (cap_octaves): a pinned result array is stale
+    int64_t grows = 0;            // list growths since creation (each one ran its image again)
     KpRecord *host_out = nullptr; // pinned result array of the call being enqueued (zero-copy delivery), or null
     int host_cap = 0;
     bool desc_rows = true;        // descriptor windows fit the row tables of descriptor_kernel (R <= SIFT_DESC_MAXRAD for this init_sigma)
@@ -254,9 +231,10 @@ struct siftmi_plan {
     bool have_init = false;
     std::vector<Event> events;
     size_t n_events = 0;
-    hipEvent_t ev_first = nullptr, ev_last = nullptr, ev_last_b = nullptr;
+    hipEvent_t ev_first = nullptr, ev_last[3] = {nullptr, nullptr, nullptr};
     float last_min = 0, last_max = 0;
     int64_t last_count = 0;
+    int last_overflow = 0;
     std::vector<void *> allocs;
 
     template <class T> int alloc(T **p, size_t nbytes) {
@@ -265,6 +243,16 @@ struct siftmi_plan {
         if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu bytes): %s", nbytes, hipGetErrorString(e));
         allocs.push_back(q);
         bytes += (int64_t)nbytes;
+        *p = (T *)q;
+        return SIFTMI_OK;
+    }
+    // a buffer that may be replaced by a larger one later (not in `allocs`: freed by its owner)
+    template <class T> int regrow(T **p, size_t old_bytes, size_t new_bytes) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, new_bytes ? new_bytes : 16);
+        if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipMalloc(%zu bytes): %s", new_bytes, hipGetErrorString(e));
+        if (*p) { (void)hipFree(*p); bytes -= (int64_t)old_bytes; }
+        bytes += (int64_t)new_bytes;
         *p = (T *)q;
         return SIFTMI_OK;
     }
@@ -311,40 +299,15 @@ void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, 
     hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT, TX, TY, VR>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm, half);
 }
 
-// Tile shape.  Planes that reach this kernel are narrower than 1024 columns or shorter than 512 rows (larger ones take
-// the marching kernels); on all of them the 32 x 16 tile measured fastest (whole call, MI355X: 512^2 0.75 / 0.52 /
-// 0.44 ms and 1020^2 0.90 / 0.63 / 0.53 ms for 128x64 / 64x32 / 32x16), so the larger shapes are kept for experiments.
-inline int blur_tile_class(const Options &opt, int, int) { return opt.tile > 0 ? opt.tile : 3; }
-
+// Tile shape: planes that reach this kernel are narrower than 1024 columns or shorter than 512 rows (larger ones take the
+// marching kernel); on all of them the 32 x 16 tile measured fastest (whole call, MI355X, round 2: 512^2 0.75 / 0.52 / 0.44 ms
+// and 1020^2 0.90 / 0.63 / 0.53 ms for 128x64 / 64x32 / 32x16 tiles).
 template <int N, bool NORM, int DT = 0>
 void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
-    switch (blur_tile_class(opt, W, H)) {
-#ifdef SIFT_DEV_VARIANTS       // the larger tiles lost on every plane that reaches this kernel: development builds only
-        case 1: launch_blur_geom<N, NORM, DT, 128, 64, 8>(st, in, out, W, H, ta, mm, half); break;
-        case 2: launch_blur_geom<N, NORM, DT, 64, 32, 8>(st, in, out, W, H, ta, mm, half); break;
-#endif
-        default: launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm, half); break;
-    }
-}
-
-template <int N, bool NORM, int NT, int DT = 0>
-void launch_march_nt(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm) {
-    using G = MarchGeom<N, NT>;
-    TapsArg<N> ta;
-    for (int i = 0; i < N; i++) ta.t[i] = taps[i];
-    const int gx = (W + G::TX - 1) / G::TX;
-    // pick the segment height: enough workgroups to fill 256 CUs, warm-up overhead (N-1)/rows kept low
-    const int want_wgs = opt.march_wgs > 0 ? opt.march_wgs : 1024 * 128 / NT;
-    int want_segments = (want_wgs + gx - 1) / gx;
-    int rows = (H + want_segments - 1) / want_segments;
-    int nblocks = (rows + (N - 1) + N - 1) / N;
-    if (nblocks < 3) nblocks = 3;
-    if (opt.march_nb > 0) nblocks = opt.march_nb;
-    const int rows_out = nblocks * N - (N - 1);
-    dim3 grid((unsigned)gx, (unsigned)((H + rows_out - 1) / rows_out));
-    hipLaunchKernelGGL((blur_march_kernel<N, NORM, NT, DT>), grid, dim3(NT), (size_t)G::LDS_BYTES, st, in, out, W, H, nblocks, ta, mm);
+    (void)opt;
+    launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm, half);
 }
 
 // team form of the marching blur (blur_team_kernel): S sub-blocks per accumulator period, `wgs` workgroups wanted.
@@ -373,32 +336,15 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
     while (covered(b, m) < need) m++;                // m <= S
     const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
     dim3 grid((unsigned)gx, (unsigned)gy);
-#ifdef SIFT_DEV_VARIANTS
-    if constexpr (!NORM && DT == 0) {
-        if (opt.glds) {            // LDS-DMA staging (k_pyramid.hpp: blur_glds_kernel), plain f32 planes without normalisation
-            hipLaunchKernelGGL((blur_glds_kernel<N, S>), grid, dim3(256), (size_t)4 * G::LDS_BYTES, st, (const float *)in, out, W, H, nblocks,
-                               last_subs, rows_out, ta, half);
-            return;
-        }
-    }
-#endif
     hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
                        rows_out, ta, mm, half);
 }
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
-// plane (tools/ubench/blur_team.hip: 31 / 38 / 41 / 47 / 65 us against 33 / 43 / 45 / 53 / 73 us for the one-block form);
-// option "team" = 0 falls back to the one-block marching kernel.
-// returns whether `half` (the fused octave hand-off) was written: the one-block marching form does not do it
+// plane (tools/ubench/blur_team.hip: 31 / 38 / 41 / 47 / 65 us against 33 / 43 / 45 / 53 / 73 us for the one-block form of round 1).
+// returns whether `half` (the fused octave hand-off) was written
 template <int N, bool NORM, int DT = 0>
 bool launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
-#ifdef SIFT_DEV_VARIANTS       // the one-block marching form (options "team" = 0, "march_nt"): development builds only
-    if (!opt.team) {
-        if (opt.march_nt == 64) launch_march_nt<N, NORM, 64, DT>(opt, st, in, out, W, H, taps, mm);
-        else launch_march_nt<N, NORM, 128, DT>(opt, st, in, out, W, H, taps, mm);
-        return false;
-    }
-#endif
     constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
     launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024, half);
     return half != nullptr;
@@ -529,55 +475,139 @@ OctaveTable octave_table(const siftmi_plan *p) {
     return tab;
 }
 
-// extrema of the three detection scales + sub-pixel refinement of one octave; survivors are appended to the
-// image-wide refined list (tagged with the octave)
-// band < 0: the whole octave.  band >= 0 (of nbands, octave 0 of a large frame): the band's strips only, candidates
-// appended behind the previous band's, refinement from there on, and mark_kp_kernel closes the band's refined range.
-void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int band = -1, int nbands = 1) {
+// ---- list capacities -----------------------------------------------------------------------------------------------
+// The reference gives EVERY OCTAVE a keypoint buffer of kpsize = H*W / PIX_PER_KP entries and one counter, reset per octave
+// (plan.py:243, 797-804): the candidates of a detection scale are appended behind the octave's oriented keypoints so far,
+// and the oriented keypoints of the scale behind those.  An image may therefore return up to kpsize records per octave.
+// Here the lists of a group start at kpsize entries and grow when an image needs more (the image is then run again), up
+// to what that rule can ever admit; `reference_overflow` evaluates the rule itself from the per-scale counts.
+int64_t list_limit(const siftmi_plan *p, int what, int g) {      // what: 0 candidates, 1 refined, 2 oriented, 3 records
+    const int64_t K = p->kpsize, O = std::max(1, p->n_oct);
+    int64_t lim = what == 0 ? 3 * K : (what == 1 ? 3 * K * (g == 2 ? O : 1) : (what == 2 ? K * (g == 2 ? O : 1) : K * O));
+    return std::min<int64_t>(lim, 0x7fffff00);
+}
+
+// c == null: the initial allocation.  Else: grow every list the image behind `c` (its counters) has outrun.  *grown says
+// whether anything changed (the image has to run again: what lies behind a cut list was never produced).
+void drain_streams(siftmi_plan *p);
+int grow_lists(siftmi_plan *p, const Counters *c, bool *grown = nullptr) {
+    if (grown) *grown = false;
+    bool drained = c == nullptr;
+    // nothing of the plan may be in flight while a buffer is replaced (another ending stream may still be copying its counters)
+    auto quiesce = [&]() { if (!drained) { drain_streams(p); drained = true; } };
+    const bool can_split = p->n_oct > 0 && march_plane(p->ow[0], p->oh[0]);
+    auto want = [&](int64_t cap, int64_t need, int64_t limit) {
+        if (need <= cap) return cap;
+        if (!c) return std::min<int64_t>(limit, need);                        // creation: exactly the reference's kpsize
+        return std::min<int64_t>(limit, std::max<int64_t>(need + need / 4 + 64, cap));
+    };
+    for (int g = 0; g < SIFT_GROUPS; g++) {
+        if (g == 1 && !can_split) continue;
+        GroupLists &G = p->grp[g];
+        int64_t need_cand = p->kpsize, need_kp = p->kpsize, need_out = p->kpsize;
+        if (c) {
+            need_cand = g == 0 ? c->n_cand[0] : (g == 1 ? c->n_cand[SIFT_MAX_OCTAVES] : 0);
+            if (g == 2) for (int o = 1; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) need_cand = std::max<int64_t>(need_cand, c->n_cand[o]);
+            need_kp = c->g_kp[g]; need_out = c->g_out[g];
+        }
+        const int64_t cc = want(G.cap_cand, need_cand, list_limit(p, 0, g)), ck = want(G.cap_kp, need_kp, list_limit(p, 1, g)),
+                      co = want(G.cap_out, need_out, list_limit(p, 2, g));
+        int rc = SIFTMI_OK;
+        if (cc != G.cap_cand || ck != G.cap_kp || co != G.cap_out) quiesce();
+        if (cc != G.cap_cand) { if ((rc = p->regrow(&G.cand, (size_t)G.cap_cand * 16, (size_t)cc * 16))) return rc; G.cap_cand = cc; if (grown) *grown = true; }
+        if (ck != G.cap_kp) {
+            if ((rc = p->regrow(&G.kp, (size_t)G.cap_kp * 16, (size_t)ck * 16)) || (rc = p->regrow(&G.kp_aux, (size_t)G.cap_kp * 4, (size_t)ck * 4))) return rc;
+            G.cap_kp = ck; if (grown) *grown = true;
+        }
+        if (co != G.cap_out) {
+            if ((rc = p->regrow(&G.okp, (size_t)G.cap_out * 16, (size_t)co * 16)) || (rc = p->regrow(&G.oaux, (size_t)G.cap_out * 4, (size_t)co * 4)) ||
+                (rc = p->regrow(&G.ord, (size_t)G.cap_out * 12, (size_t)co * 12))) return rc;
+            G.cap_out = co; if (grown) *grown = true;
+        }
+    }
+    const int64_t cr = want(p->cap_rec, c ? (int64_t)c->n_rec : p->kpsize, list_limit(p, 3, 0));
+    if (cr != p->cap_rec) {
+        quiesce();
+        int rc = p->regrow(&p->records, (size_t)p->cap_rec * sizeof(KpRecord), (size_t)cr * sizeof(KpRecord));
+        if (rc) return rc;
+        p->cap_rec = cr; if (grown) *grown = true;
+    }
+    if (grown && *grown) p->grows++;
+    return SIFTMI_OK;
+}
+
+// The reference's capacity rule on the counts of an image (see Counters::c_scale): per octave, with `last` the oriented
+// keypoints of the scales before, local_maxmin of scale s leaves the counter at last + candidates(s) and the orientation
+// pass at last + oriented(s); either beyond kpsize means the reference dropped entries (image.cl:203-205,
+// orientation_cpu.cl:150-172, plan.py:771 only warns).  oracle/sift_oracle.c: so_keypoints applies the same rule.
+bool reference_overflow(const siftmi_plan *p, const Counters &c) {
+    for (int o = 0; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) {
+        int64_t last = 0;
+        for (int s = 0; s < 3; s++) {
+            if (last + c.c_scale[o][s] > p->kpsize) return true;
+            last += c.o_scale[o][s];
+            if (last > p->kpsize) return true;
+        }
+    }
+    return false;
+}
+
+// Group of an octave: octave 0 alone (group 0; groups 0 and 1 when it is split by scale), every later octave in group 2.
+int group_of(const siftmi_plan *, int oct) { return oct == 0 ? 0 : 2; }
+
+// Extrema of the detection scales + sub-pixel refinement of one octave; survivors are appended to the refined list of
+// the octave's group (tagged with the octave).
+// part 0: the three scales in one pass.  Octave 0 split by scale (Options::split0): part 1 = scale 1 (planes 0-3, group 0),
+// part 2 = scales 2-3 (planes 1-5, group 1), each with its own candidate list and counter.
+void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int part = 0) {
     const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
     const int octsize = 1 << oct;
+    const int g = part == 2 ? 1 : group_of(p, oct);
+    GroupLists &G = p->grp[g];
+    p->groups_cur |= 1u << g;
     char lab[96];
     BlurPlanes bp;
     for (int s = 0; s < 6; s++) bp.p[s] = p->plane(oct, s);
     const int border = p->par.border_dist;
-    const int kcap = (int)p->kpsize;
-    if (W > 2 * border && H > 2 * border) {
-        const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border, p->opt.ext_strips);
-        const int nx = (W - 2 * border + 61) / 62, ny_all = (H - 2 * border + rows - 1) / rows;
-        int y_lo = -1, y_hi = -1, ny = ny_all;
-        if (band >= 0) {                     // whole strips: band b takes strips [b * ny / B, (b + 1) * ny / B)
-            const int s0 = (int)((int64_t)band * ny_all / nbands), s1 = (int)((int64_t)(band + 1) * ny_all / nbands);
-            y_lo = border + s0 * rows; y_hi = std::min(border + s1 * rows, H - border);
-            ny = s1 - s0;
-        }
-        const int blocks = std::max(1, (nx * ny + 3) / 4);
-        const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
-        const RefineArgs ra = {p->par.peak_thresh, (float)p->par.init_sigma, p->kp_of(oct), p->kp_aux_of(oct), p->kp_counter_of(oct), kcap, oct};
-        // One launch detects and refines (the survivors of the edge test are refined by the wave that parked them: no
-        // candidate list, no second launch) unless every stage is bracketed on its own (full profile) or option
-        // "fused_refine" says otherwise (0: never, 1: planes below 1400^2, 2: every plane).
-        const bool fused = band < 0 && p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
-        if (fused) {
-            snprintf(lab, sizeof lab, "local_maxmin+interp_keypoint %d", oct);
-            Scope sc(p, lab, false, 0, st);
-            hipLaunchKernelGGL(extrema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                               contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra, -1, -1);
-            return;
-        }
-        snprintf(lab, sizeof lab, "local_maxmin %d", oct);
+    const int ccap = (int)G.cap_cand, kcap = (int)G.cap_kp;
+    int *n_cand = &p->cnt->n_cand[part == 2 ? SIFT_MAX_OCTAVES : oct];
+    if (!(W > 2 * border && H > 2 * border)) return;
+    const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border, p->opt.ext_strips);
+    const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
+    const int blocks = std::max(1, (nx * ny + 3) / 4);
+    const float edth = (octsize <= 1) ? p->par.edge_thresh0 : p->par.edge_thresh;   // image.cl:193, plan.py:633-634
+    const RefineArgs ra = {p->par.peak_thresh, (float)p->par.init_sigma, G.kp, G.kp_aux, &p->cnt->g_kp[g], kcap, oct, &p->cnt->c_scale[oct][0]};
+    // One launch detects and refines (the survivors of the edge test are refined by the wave that parked them: no
+    // candidate list, no second launch) unless every stage is bracketed on its own (full profile) or option
+    // "fused_refine" says otherwise (0: never, 1: planes below 1400^2, 2: every plane).
+    const bool fused = part == 0 && p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
+    if (fused) {
+        snprintf(lab, sizeof lab, "local_maxmin+interp_keypoint %d", oct);
         Scope sc(p, lab, false, 0, st);
-        hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                           contrast_threshold(p->par), edth, p->cand, &p->cnt->n_cand[oct], kcap, ra, y_lo, y_hi);
+        hipLaunchKernelGGL(extrema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                           contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
+        return;
     }
     {
-        snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
+        snprintf(lab, sizeof lab, "local_maxmin %d%s", oct, part == 1 ? " scale 1" : (part == 2 ? " scales 2-3" : ""));
         Scope sc(p, lab, false, 0, st);
-        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)p->cand,
-                           (const int *)&p->cnt->n_cand[oct], kcap, p->par.peak_thresh, (float)p->par.init_sigma, p->kp_of(oct),
-                           p->kp_aux_of(oct), p->kp_counter_of(oct), kcap, oct, &p->cnt->overflow,
-                           band >= 0 ? (const int *)&p->cnt->grp_cand_start[band] : (const int *)nullptr);
+        if (part == 1)
+            hipLaunchKernelGGL((extrema_kernel<false, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                               contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
+        else if (part == 2)
+            hipLaunchKernelGGL((extrema_kernel<false, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                               contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
+        else
+            hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                               contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
     }
-    if (band >= 0) hipLaunchKernelGGL(mark_kp_kernel, dim3(1), dim3(1), 0, st, p->cnt, band, kcap, oct, kcap);
+    {
+        snprintf(lab, sizeof lab, "interp_keypoint+compact %d%s", oct, part == 1 ? " scale 1" : (part == 2 ? " scales 2-3" : ""));
+        Scope sc(p, lab, false, 0, st);
+        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)G.cand,
+                           (const int *)n_cand, ccap, p->par.peak_thresh, (float)p->par.init_sigma, G.kp,
+                           G.kp_aux, &p->cnt->g_kp[g], kcap, oct, &p->cnt->c_scale[oct][0]);
+    }
 }
 
 // First octave of the run that octave_tail_kernel takes (k_tail.hpp), or n_oct when it takes none: octaves >= 1 whose
@@ -629,49 +659,37 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
             have = lds;
         }
     }
-    const int kcap = (int)p->kpsize;
+    GroupLists &G = p->grp[2];                 // the tail's octaves are later octaves (or the whole image): group 2
+    p->groups_cur |= 1u << 2;
     hipLaunchKernelGGL(octave_tail_kernel, dim3((unsigned)a.n), dim3(SIFT_TAIL_THREADS), lds, st, a, p->par.border_dist,
                        contrast_threshold(p->par), p->par.peak_thresh, (float)p->par.init_sigma, p->tail_cand, p->tail_cand_cap,
-                       p->cnt->n_cand, p->cnt->tail_ready, p->kp_of(first), p->kp_aux_of(first), p->kp_counter_of(first), kcap, &p->cnt->overflow, &p->cnt->tail_timeout);
+                       p->cnt->n_cand, p->cnt->tail_ready, G.kp, G.kp_aux, &p->cnt->g_kp[2], (int)G.cap_kp, &p->cnt->c_scale[0][0], &p->cnt->tail_timeout);
     return SIFTMI_OK;
 }
 
-// orientation of every refined keypoint of one group, then the group's record range is frozen (mark_group_kernel).
-// banded: the group is a band of octave 0 -- its refined range was frozen by mark_kp_kernel, the next band is being refined.
-void launch_orient_group(siftmi_plan *p, int group, hipStream_t st, bool banded) {
-    const int kcap = (int)p->kpsize;
+// orientation of every refined keypoint of one group (its refinement launches precede this one on `st`)
+void launch_orient_group(siftmi_plan *p, int group, hipStream_t st) {
     const OctaveTable tab = octave_table(p);
+    GroupLists &G = p->grp[group];
     char lab[96];
-    {
-        snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
-        Scope sc(p, lab, false, 0, st);
-        const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
-        const bool maps = group < p->later_group ? p->maps_g0 : p->maps_g1;
-        if (maps)
-            hipLaunchKernelGGL(orientation_kernel<true>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                               (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
-                               banded ? 1 : 0, p->opt.ori_small_blocks);
-        else
-            hipLaunchKernelGGL(orientation_kernel<false>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                               (const float4 *)p->kp, (const int *)p->kp_scale, p->cnt, group, kcap, p->okp, p->oaux, kcap, p->opt.ori_team,
-                               banded ? 1 : 0, p->opt.ori_small_blocks);
-    }
-    // Octave 0 of a frame with few keypoints per pixel is described largest window first (mark_group_kernel orders the
-    // hand-out; k_keypoint.hpp).  Measured: headline frame -2.1 %, 2048^2 white noise -1.2 %; on keypoint-rich frames the
-    // list order wins (neighbours in the list are neighbours in the image and share their window pixels in the caches:
-    // 1024^2 smoothed noise +5 % when ordered), hence the bound of one keypoint per `desc_sort_density` pixels; the later
-    // octaves' groups +-0.
-    const bool octave0 = group < p->later_group && p->n_oct > 0;
-    const long long px0 = p->n_oct > 0 ? (long long)p->ow[0] * p->oh[0] : 0;
-    const int sort_below = (p->opt.desc_sort > 0 && octave0) ? (int)std::min<long long>(p->opt.desc_sort, px0 / std::max(1, p->opt.desc_sort_density)) : 0;
-    hipLaunchKernelGGL(mark_group_kernel, dim3(1), dim3(SIFT_MARK_THREADS), 0, st, p->cnt, group, kcap, kcap, banded ? 0 : 1,
-                       (const float4 *)p->okp, (const int *)p->oaux, sort_below > 0 ? p->order : nullptr, std::max(2, p->opt.desc_team), sort_below);
+    snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
+    Scope sc(p, lab, false, 0, st);
+    const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
+    const bool maps = group < 2 ? p->maps_g0 : p->maps_g1;
+    if (maps)
+        hipLaunchKernelGGL(orientation_kernel<true>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
+                           (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, G.ord, (int)G.cap_out,
+                           p->opt.ori_team, p->opt.ori_small_blocks);
+    else
+        hipLaunchKernelGGL(orientation_kernel<false>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
+                           (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, G.ord, (int)G.cap_out,
+                           p->opt.ori_team, p->opt.ori_small_blocks);
 }
 
 // descriptors of one group's oriented keypoints
 void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
-    const int kcap = (int)p->kpsize;
     const OctaveTable tab = octave_table(p);
+    GroupLists &G = p->grp[group];
     char lab[96];
     snprintf(lab, sizeof lab, "descriptors group %d", group);
     Scope sc(p, lab, false, 0, st);
@@ -681,23 +699,26 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
     // kernels (shorter detection chain, 4 workgroups per CU by registers) the unthrottled launch is faster
     // (0.96 against 1.01 ms per 4096^2 frame), so the default is 0.
     const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
-    // a small group 0 of a LARGE frame leaves room for the later octaves' chain, which ends such an image (4096^2 headline
-    // -2.2 %, 4096^2 with every octave -2.5 %); on a 1024^2 frame that chain is short and the same cut costs 2 %
-    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
+    // a small group of octave 0 of a LARGE frame leaves room for the later octaves' chain, which ends such an image (4096^2
+    // headline -2.2 %, 4096^2 with every octave -2.5 %); on a 1024^2 frame that chain is short and the same cut costs 2 %
+    const int small_blocks = (group < 2 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
+    const int ocap = (int)G.cap_out, rcap = (int)std::min<int64_t>(p->cap_rec, 0x7fffffff);
     if (p->desc_rows && !p->opt.desc_stream) {
         // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
         // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
-        const bool maps = group < p->later_group ? p->maps_g0 : p->maps_g1;
+        const bool maps = group < 2 ? p->maps_g0 : p->maps_g1;
         if (maps)
             // (the MAPS form of a dense group wants every workgroup of the launch: 154 k keypoints 4.68 ms at 832, 4.48 at 960)
             hipLaunchKernelGGL(descriptor_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks, (const int *)p->order);
+                               (const float4 *)G.okp, (const int *)G.oaux, p->cnt, group, 0, 0, ocap, p->records, rcap, p->host_out, p->host_cap,
+                               p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks, (const int *)G.ord, p->opt.desc_bucket);
         else
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                               (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks, (const int *)p->order);
+                               (const float4 *)G.okp, (const int *)G.oaux, p->cnt, group, 0, 0, ocap, p->records, rcap, p->host_out, p->host_cap,
+                               p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks, (const int *)G.ord, p->opt.desc_bucket);
     } else
         hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
-                           (const float4 *)p->okp, (const int *)p->oaux, (const Counters *)p->cnt, group, 0, 0, kcap, p->records, p->host_out, p->host_cap);
+                           (const float4 *)G.okp, (const int *)G.oaux, p->cnt, group, 0, 0, ocap, p->records, rcap, p->host_out, p->host_cap);
 }
 
 // gradient maps of the octaves [oct_lo, oct_hi) (their pyramids exist on `st`)
@@ -713,39 +734,15 @@ void launch_gradient_maps(siftmi_plan *p, int oct_lo, int oct_hi, hipStream_t st
     hipLaunchKernelGGL(gradient_maps_kernel, dim3(blocks), dim3(256), 0, st, tab, oct_lo, oct_hi, total, p->gmap, p->omap);
 }
 
-// Fused form (option "fused_kp"): ONE launch orients and describes every refined keypoint of the group's own list
-// (k_descriptor.hpp: keypoint_fused_kernel).  No orientation launch, no mark_group_kernel, no event between the groups.
-void launch_fused_group(siftmi_plan *p, int group, hipStream_t st) {
-    const int kcap = (int)p->kpsize;
-    const OctaveTable tab = octave_table(p);
-    char lab[96];
-    snprintf(lab, sizeof lab, "orientation_assignment + descriptors group %d", group);
-    Scope sc(p, lab, false, 0, st);
-    const int desc_blocks = p->opt.desc_blocks;
-    const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
-    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
-    const bool maps = group == 0 ? p->maps_g0 : p->maps_g1;
-    const float4 *kp = group ? p->okp : p->kp;
-    const int *aux = group ? p->oaux : p->kp_scale;
-#ifdef SIFT_DEV_VARIANTS
-    if (maps)
-        hipLaunchKernelGGL(keypoint_fused_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab, p->par.ori_sigma, kp, aux,
-                           p->cnt, group, kcap, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_dynamic, desc_blocks, small_blocks);
-    else
-        hipLaunchKernelGGL(keypoint_fused_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab, p->par.ori_sigma, kp, aux,
-                           p->cnt, group, kcap, kcap, p->records, p->host_out, p->host_cap, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
-#else
-    (void)kcap; (void)tab; (void)desc_pad; (void)small_blocks; (void)maps; (void)kp; (void)aux;
-#endif
-}
-
-// orientation + descriptor for every refined keypoint of one group of octaves, on one stream; `mark_event`: recorded once
-// the group's ranges are frozen (the next group may start appending)
-void launch_describe_group(siftmi_plan *p, int group, hipStream_t st, hipEvent_t mark_event = nullptr) {
-    if (p->fused) { launch_fused_group(p, group ? 1 : 0, st); return; }
-    launch_orient_group(p, group, st, false);
-    if (mark_event) hipEventRecord(mark_event, st);
+// orientation + descriptors of one group, on one stream, ending with the read-back of the counters into pinned block `slot`
+int launch_describe_group(siftmi_plan *p, int group, hipStream_t st, int slot) {
+    p->groups_cur |= 1u << group;
+    launch_orient_group(p, group, st);
     launch_descriptor_group(p, group, st);
+    if (p->profile > 1) hipEventRecord(p->ev_last[slot], st);
+    HIPCHK(hipMemcpyAsync(&p->hb->c[slot], p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    p->wait_s[slot] = st;
+    return SIFTMI_OK;
 }
 
 }  // namespace
@@ -766,13 +763,6 @@ int siftmi_dev_phase(uint64_t *out32, int32_t reset) {
 #endif
 const char *siftmi_version(void) { return "sift_pyocl_amd 0.1 (gfx950)"; }
 
-#ifdef SIFT_ABLATE
-static void apply_ablate() {
-    const char *e = getenv("SIFTMI_ABLATE");
-    int v = e ? atoi(e) : 0;
-    hipMemcpyToSymbol(HIP_SYMBOL(siftk::g_ablate), &v, sizeof v);
-}
-#endif
 
 int siftmi_device_count(void) {
     int n = 0;
@@ -841,9 +831,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     }
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
     if (!rc && (prio ? hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&p->stream3, hipStreamNonBlocking)) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipStreamCreate failed");
-    if (!rc && (hipEventCreateWithFlags(&p->ev_mark0, SIFT_SYNC_EVENT) != hipSuccess ||
-                hipEventCreateWithFlags(&p->ev_grp1, SIFT_SYNC_EVENT) != hipSuccess ||
-                hipEventCreateWithFlags(&p->ev_det, SIFT_SYNC_EVENT) != hipSuccess)) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
+    if (!rc && hipEventCreateWithFlags(&p->ev_p3, SIFT_SYNC_EVENT) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
     p->overlap = true;
     for (int o = 0; o < p->n_oct && !rc; o++) {
         hipEvent_t e;
@@ -857,23 +845,23 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
     // two counter blocks, used by alternate images: the min/max pass of an image resets the other one for its successor
     if (!rc) rc = p->alloc(&p->cnt_pair, 2 * sizeof(Counters));
     if (!rc) { p->cnt = p->cnt_pair; p->mm = p->cnt->mm; }   // (mm: device address of the min/max slots inside the counter block)
-    if (!rc) rc = p->alloc(&p->cand, (size_t)p->kpsize * sizeof(float4));
     // a tail octave (<= SIFT_TAIL_MAX_PIXELS samples, 3 scales) cannot hold more candidates than this
-    p->tail_cand_cap = (int)std::min<int64_t>(p->kpsize, 3 * SIFT_TAIL_MAX_PIXELS);
+    p->tail_cand_cap = 3 * SIFT_TAIL_MAX_PIXELS;
     if (!rc) rc = p->alloc(&p->tail_cand, (size_t)SIFT_TAIL_MAX_OCT * p->tail_cand_cap * sizeof(float4));
-    if (!rc) rc = p->alloc(&p->kp, (size_t)p->kpsize * sizeof(float4));
-    if (!rc) rc = p->alloc(&p->kp_scale, (size_t)p->kpsize * sizeof(int));
-    if (!rc) rc = p->alloc(&p->okp, (size_t)p->kpsize * sizeof(float4));
-    if (!rc) rc = p->alloc(&p->oaux, (size_t)p->kpsize * sizeof(int));
-    if (!rc) rc = p->alloc(&p->order, (size_t)p->kpsize * sizeof(int));
-    if (!rc) rc = p->alloc(&p->records, (size_t)p->kpsize * sizeof(KpRecord));
+    // The lists start at the reference's kpsize (plan.py:243: its capacity PER OCTAVE) and grow when an image needs more
+    // (grow_lists): a frame of the default PIX_PER_KP never does.  Octave 0 in two groups needs group 1's lists too:
+    // large planes only (the planes the marching blur takes).
+    if (!rc) rc = grow_lists(p, nullptr);
     if (!rc) rc = compute_schedule(p);
     if (!rc) {
-        hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt_pair);
-        hipLaunchKernelGGL(begin_image_kernel, dim3(1), dim3(64), 0, p->stream, p->cnt_pair + 1);
-        if (hipStreamSynchronize(p->stream) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "counter initialisation failed");
+        // both blocks all zero, min / max slots at their identities (minmax_reset_next does the same for every later image)
+        Counters zero;
+        memset(&zero, 0, sizeof zero);
+        zero.mm[0] = 0xffffffffu;
+        if (hipMemcpy(p->cnt_pair, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->cnt_pair + 1, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "counter initialisation failed");
     }
-    if (!rc) { hipEventCreate(&p->ev_first); hipEventCreate(&p->ev_last); hipEventCreate(&p->ev_last_b); }
+    if (!rc) { hipEventCreate(&p->ev_first); for (hipEvent_t &e : p->ev_last) hipEventCreate(&e); }
     if (rc) { std::string keep = g_err; siftmi_plan_destroy(p); g_err = keep; return rc; }
     *out = p;
     return SIFTMI_OK;
@@ -885,16 +873,13 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
     if (p->stream3) { hipStreamSynchronize(p->stream3); hipStreamDestroy(p->stream3); }
-    if (p->stream4) { hipStreamSynchronize(p->stream4); hipStreamDestroy(p->stream4); }
-    for (hipEvent_t e : p->ev_kp) hipEventDestroy(e);
-    for (hipEvent_t e : p->ev_out) hipEventDestroy(e);
-    if (p->ev_mark0) hipEventDestroy(p->ev_mark0);
     if (p->ev_p3) hipEventDestroy(p->ev_p3);
-    if (p->ev_grp1) hipEventDestroy(p->ev_grp1);
     if (p->ev_maps0) hipEventDestroy(p->ev_maps0);
-    if (p->ev_det) hipEventDestroy(p->ev_det);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
+    for (GroupLists &G : p->grp)
+        for (void *q : {(void *)G.kp, (void *)G.kp_aux, (void *)G.okp, (void *)G.oaux, (void *)G.ord, (void *)G.cand}) if (q) hipFree(q);
+    if (p->records) hipFree(p->records);
     if (p->hb) hipHostFree(p->hb);
     if (p->ev_join) hipEventDestroy(p->ev_join);
     if (p->warp_in) hipFree(p->warp_in);
@@ -903,8 +888,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->ev_wb) hipEventDestroy(p->ev_wb);
     for (Event &e : p->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (p->ev_first) hipEventDestroy(p->ev_first);
-    if (p->ev_last) hipEventDestroy(p->ev_last);
-    if (p->ev_last_b) hipEventDestroy(p->ev_last_b);
+    for (hipEvent_t e : p->ev_last) if (e) hipEventDestroy(e);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
     return SIFTMI_OK;
@@ -915,6 +899,13 @@ int siftmi_plan_info(const siftmi_plan *p, int32_t *n_octaves, int64_t *kpsize, 
     if (n_octaves) *n_octaves = p->n_oct;
     if (kpsize) *kpsize = p->kpsize;
     if (bytes_allocated) *bytes_allocated = p->bytes;
+    return SIFTMI_OK;
+}
+
+int siftmi_plan_capacity(const siftmi_plan *p, int64_t *records, int64_t *growths) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (records) *records = p->cap_rec;
+    if (growths) *growths = p->grows;
     return SIFTMI_OK;
 }
 
@@ -942,10 +933,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     if (n == "fused_convert") o.fused_convert = v != 0;
     else if (n == "overlap") { o.overlap = v != 0; p->overlap = o.overlap; }
     else if (n == "march") o.march = v != 0;
-    else if (n == "team") o.team = v != 0;
-    else if (n == "march_nt") { if (v != 64 && v != 128) return fail(SIFTMI_EINVAL, "march_nt must be 64 or 128"); o.march_nt = v; }
     else if (n == "march_wgs") o.march_wgs = v > 0 ? v : 0;
-    else if (n == "march_nb") o.march_nb = v >= 3 ? v : 0;
     else if (n == "ori_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_blocks must be >= 1"); o.ori_blocks = v; }
     else if (n == "ori_pad") o.ori_pad = v > 0 ? v : 0;
     else if (n == "desc_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_blocks must be >= 1"); o.desc_blocks = v; }
@@ -953,40 +941,26 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "desc_stream") o.desc_stream = v != 0;
     else if (n == "mm_threads") { if (v != 256 && v != 512 && v != 1024) return fail(SIFTMI_EINVAL, "mm_threads must be 256, 512 or 1024"); o.mm_threads = v; }
     else if (n == "mm_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "mm_blocks must be >= 1"); o.mm_blocks = v; }
-    else if (n == "chain0") o.chain0 = v != 0;
     else if (n == "ori_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_small_blocks must be >= 1"); o.ori_small_blocks = v; }
-#ifdef SIFT_DEV_VARIANTS
-    else if (n == "bands") { if (v < 0 || v >= SIFT_GROUPS) return fail(SIFTMI_EINVAL, "bands must be in 0..%d", SIFT_GROUPS - 1); o.bands = v; }
-    else if (n == "early_chain") o.early_chain = v != 0;
-#endif
-    else if (n == "tile") o.tile = (int)v;
     else if (n == "ext_rows") o.ext_rows = (int)v;
     else if (n == "ext_strips") { if (v < 1) return fail(SIFTMI_EINVAL, "ext_strips must be >= 1"); o.ext_strips = (int)v; }
     else if (n == "tail") o.tail = v != 0;
     else if (n == "tail_pixels") { if (v < 1 || v > SIFT_TAIL_MAX_PIXELS) return fail(SIFTMI_EINVAL, "tail_pixels must be in 1..%d", SIFT_TAIL_MAX_PIXELS); o.tail_pixels = (int)v; }
-    else if (n == "early_pyr") o.early_pyr = v != 0;
-    else if (n == "split_detect") o.split_detect = v != 0;
     else if (n == "desc_team") o.desc_team = v > 0 ? v : 0;
     else if (n == "desc_dynamic") o.desc_dynamic = v != 0;
     else if (n == "ori_team") o.ori_team = v > 0 ? v : 0;
     else if (n == "fused_shrink") o.fused_shrink = v != 0;
-#ifdef SIFT_DEV_VARIANTS
-    else if (n == "fused_kp") o.fused_kp = v != 0;
-#endif
     else if (n == "fused_refine") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fused_refine must be 0, 1 or 2"); o.fused_refine = (int)v; }
     else if (n == "maps") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "maps must be 0 (never), 1 (always) or 2 (by the previous image)"); o.maps = v; }
     else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
     else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
-    else if (n == "desc_sort_density") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_sort_density must be >= 1"); o.desc_sort_density = v; }
-    else if (n == "desc_sort") { if (v < 0) return fail(SIFTMI_EINVAL, "desc_sort must be >= 0"); o.desc_sort = v; }
+    else if (n == "desc_bucket") { if (v < 0) return fail(SIFTMI_EINVAL, "desc_bucket must be >= 0"); o.desc_bucket = v; }
+    else if (n == "split0") o.split0 = v != 0;
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
     else if (n == "host_timing") o.host_timing = v != 0;
     else if (n == "tail_fault") o.tail_fault = v > 0 ? v : 0;
-#ifdef SIFT_DEV_VARIANTS
-    else if (n == "glds") o.glds = v != 0;
-#endif
     else return fail(SIFTMI_EINVAL, "unknown option '%s'", name);
     return SIFTMI_OK;
 }
@@ -1017,16 +991,15 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_enter = tnow();
     p->n_events = 0;
-#ifdef SIFT_ABLATE
-    apply_ablate();
-#endif
     if (p->profile > 1) hipEventRecord(p->ev_first, p->stream);     // (light profile: only the blur bracket -- every event record between kernels is a bubble)
     // this image's counter block was reset by the min/max pass of the previous image (or at plan creation); the other block
     // is reset by this image's min/max pass (k_pyramid.hpp: minmax_reset_next)
+    // (the two blocks alternate only if an image never overlaps its predecessor on the same plan: plan_wait -- or a drain
+    // on an error path -- always comes between two enqueues; `in_flight` enforces it)
+    if (p->in_flight) return fail(SIFTMI_EINVAL, "the plan still has an image in flight");
     p->cnt = p->cnt_pair + p->cnt_parity;
     p->mm = p->cnt->mm;
     Counters *next_cnt = p->cnt_pair + (p->cnt_parity ^ 1);
-    p->cnt_parity ^= 1;
     constexpr int kCntWords = (int)(sizeof(Counters) / 4), kCntOnes = (int)(offsetof(Counters, mm) / 4);
     static_assert(sizeof(Counters) % 4 == 0, "Counters is a block of 32-bit words");
     const float *f32src = (const float *)src;
@@ -1063,6 +1036,8 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
                                (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes);
         }
     }
+    p->cnt_parity ^= 1;          // the pass that resets the other block is in the queue: the next image takes that block
+    p->in_flight = true;
     float *base0 = p->plane(0, 0);
     if (p->have_init) {
         // light profiling: ONE event pair around the six full-resolution blur launches (initial + five scales of
@@ -1098,45 +1073,25 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
 }
 
 // Pyramid of every octave, detection, orientation, description, read-back of the counters: the part of one image's
-// work that touches plan-owned buffers only (so it can be captured once and replayed).  Sets p->fin.
+// work that touches plan-owned buffers only.  Sets p->fin and p->wait_s.
 int enqueue_body(siftmi_plan *p) {
     char lab[96];
-    // Two chains (option "overlap"): stream `stream` carries octave 0 end to end -- pyramid, detection, orientation,
-    // descriptors, read-back of the counters: the critical path of an image, without a cross-stream hop (~12 us each) on
-    // it; `stream3` builds the pyramids of the later octaves once octave 0's exists, detects and describes them (group 1:
-    // its detection waits until group 0's orientation pass has frozen its list ranges) and ends with its own read-back.
-    // Octave planes are never rewritten, so the only ordering needed is those two events.  (Option "chain0" = 0 restores
-    // the round-1 layout: every pyramid on `stream`, octave 0's detection on `stream2`.)
+    // Streams (option "overlap"; a single-stream plan runs the same launches in this order on `stream`):
+    //   stream  : octave 0 end to end -- pyramid, detection, orientation, descriptors, read-back of the counters;
+    //   stream2 : octave 0 split by scale (option "split0", planes the marching blur takes): detection scale 1 needs planes
+    //             0-3 only, so its detection, refinement, orientation and descriptors (group 0) start when plane 3 exists,
+    //             under the octave's last two blurs, and `stream` carries scales 2-3 (group 1) behind the pyramid;
+    //             unsplit: octave 0's gradient maps beside its detection (keypoint-rich frames);
+    //   stream3 : the later octaves -- pyramids from octave 0's plane 3 on, detection, the tail launch, group 2's
+    //             orientation and descriptors.
+    // The groups have their own lists and counters and meet only in the record list (descriptor_reserve): nothing orders
+    // them but the two pyramid events.  Octave planes are never rewritten.
     const bool two = p->overlap && p->n_oct > 0;
-    const bool chain0 = two && p->opt.chain0;
     const int tail_first = tail_first_octave(p);
-    // Banded octave 0 (option "bands", large frames, chain0 layout): detection + refinement of band b on `stream` (one after
-    // the other, behind the pyramid), its orientation on `stream2` as soon as its refined range is frozen (ev_kp[b]), its
-    // descriptors on `stream4` as soon as its record range is (ev_out[b]).  Unbanded, the three phases of octave 0 are
-    // strictly serial -- 96 + 20 + 70 us on the headline frame before the first descriptor wave starts -- and the
-    // memory-bound detection never overlaps the issue-bound description.  Groups 0 .. nbands - 1 are the bands, group
-    // `later` the later octaves.
-    // DEVELOPMENT BUILDS ONLY (SIFT_DEV_VARIANTS): measured slower on every frame (Options::bands); the product path is unbanded.
-    int nbands = 0;
-#ifdef SIFT_DEV_VARIANTS
-    if (chain0 && p->opt.bands > 1 && p->n_oct > 0 && p->profile <= 1 && march_plane(p->ow[0], p->oh[0]) && tail_first != 0 &&
-        p->ow[0] > 2 * p->par.border_dist && p->oh[0] > 2 * p->par.border_dist) {
-        nbands = std::min(p->opt.bands, SIFT_GROUPS - 1);
-        if (!p->stream4) HIPCHK(hipStreamCreateWithFlags(&p->stream4, hipStreamNonBlocking));
-        while ((int)p->ev_kp.size() < nbands) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreateWithFlags(&a, SIFT_SYNC_EVENT));
-            HIPCHK(hipEventCreateWithFlags(&b, SIFT_SYNC_EVENT));
-            p->ev_kp.push_back(a); p->ev_out.push_back(b);
-        }
-    }
-#endif
-    p->bands_last = nbands;
-    const int later = nbands ? nbands : 1;         // group index of the later octaves
-    // fused per-keypoint launches: not with a stage-by-stage profile (every stage keeps its launch and label), not banded,
-    // not with windows beyond the row tables
     p->tail_first_cur = tail_first;
-    p->fused = p->opt.fused_kp && p->profile <= 1 && !nbands && p->desc_rows && !p->opt.desc_stream;
+    p->groups_cur = 0;
+    for (hipStream_t &w : p->wait_s) w = nullptr;
+    const int border = p->par.border_dist;
     // Gradient maps for the per-keypoint kernels of this image (option "maps"): large frames, by the previous image's counts
     {
         const int mode = p->opt.maps;
@@ -1146,11 +1101,9 @@ int enqueue_body(siftmi_plan *p) {
             if (o == 0) px0 = px; else px1 += px;
         }
         auto dense = [&](int count, long long pixels) { return mode == 1 || (mode == 2 && (long long)count * p->opt.maps_density >= pixels); };
-        // (a frame whose octaves all go to the tail kernel has one group, the "later" one, holding octave 0 as well)
-        if (tail_first == 0) px1 += px0;
-        const bool layout_ok = mode != 0 && p->n_oct > 0 && (!two || chain0) && (mode == 1 || march_plane(p->ow[0], p->oh[0]));
-        bool want0 = layout_ok && tail_first != 0 && dense(p->last_group0, px0);
-        bool want1 = layout_ok && (p->n_oct > 1 || tail_first == 0) && dense(p->last_group1, px1);
+        const bool layout_ok = mode != 0 && p->n_oct > 0 && (mode == 1 || march_plane(p->ow[0], p->oh[0]));
+        bool want0 = layout_ok && dense(p->last_group0, px0);
+        bool want1 = layout_ok && p->n_oct > 1 && dense(p->last_group1, px1);
         if ((want0 || want1) && !p->gmap) {
             // first keypoint-rich image of this plan: two maps of half the pyramid's size each (three planes per octave)
             float *g = nullptr, *o = nullptr;
@@ -1169,27 +1122,21 @@ int enqueue_body(siftmi_plan *p) {
                 (void)hipGetLastError();
             }
         }
-        p->maps_g0 = want0; p->maps_g1 = want1; p->later_group = later;
+        p->maps_g0 = want0; p->maps_g1 = want1;
         if (want0 && two && !p->ev_maps0) HIPCHK(hipEventCreateWithFlags(&p->ev_maps0, SIFT_SYNC_EVENT));
     }
-    auto pyramid_stream = [&](int oct) { return (chain0 && oct > 0) ? p->stream3 : p->stream; };                                   // builds an octave's planes
-    // Later octaves: the pyramid of octave o+1 needs only plane 3 of octave o, not its detection.  With "split_detect" the
-    // extrema / refinement launches of octaves >= 1 go to `stream2` (idle in the chain0 layout), each behind the event
-    // of its pyramid, and the chain on `stream3` is pyramids only until the group's description, which waits for both.
-    const bool split = chain0 && p->opt.split_detect;
-    auto detect_stream = [&](int oct) { return !two ? p->stream : (oct == 0 ? (chain0 ? p->stream : p->stream2) : (split ? p->stream2 : p->stream3)); };   // consumes them
-    bool built[SIFT_MAX_OCTAVES] = {false};
+    // Octave 0 in two groups: large planes, two streams, no stage-by-stage profile (every stage keeps one launch and label
+    // there), the lazy-gradient forms (a keypoint-rich frame builds its maps from the complete pyramid)
+    const bool split0 = two && p->opt.split0 && p->n_oct > 0 && p->profile <= 1 && !p->maps_g0 && p->grp[1].okp &&
+                        march_plane(p->ow[0], p->oh[0]) && p->ow[0] > 2 * border && p->oh[0] > 2 * border;
+    p->split_cur = split0;
+    hipStream_t later = two ? p->stream3 : p->stream;       // the later octaves' chain
     bool handed[SIFT_MAX_OCTAVES + 1] = {false};   // plane 0 of the octave was written by the blur launch of the octave above
-    // shrink + five blurs of one octave on its pyramid stream (once)
     hipEvent_t pyr0_done = nullptr;            // light profile: the blur bracket's closing event stands in for ev_pyr[0]
-    const bool early0 = chain0 && p->opt.early_chain && p->n_oct > 1 && p->profile <= 1;
-    if (early0 && !p->ev_p3) HIPCHK(hipEventCreateWithFlags(&p->ev_p3, SIFT_SYNC_EVENT));
-    auto build_pyramid = [&](int oct) -> int {
-        if (built[oct]) return SIFTMI_OK;
-        built[oct] = true;
+    int slot = 0;                              // read-back blocks used so far (one per ending stream)
+    // shrink + five blurs of one octave on stream `pyr`
+    auto build_pyramid = [&](int oct, hipStream_t pyr) -> int {
         const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
-        hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
-        if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, (early0 && p->ev_p3) ? p->ev_p3 : (pyr0_done ? pyr0_done : p->ev_pyr[0]), 0));
         if (oct > 0 && !handed[oct]) {
             const int LW = p->ow[(size_t)oct - 1];
             snprintf(lab, sizeof lab, "shrink %d", oct - 1);
@@ -1199,147 +1146,142 @@ int enqueue_body(siftmi_plan *p) {
         }
         // The octave hand-off (next[y][x] = plane 3 [2y][2x]) rides on the launch that writes plane 3, unless the next octave
         // is built by the tail kernel (which shrinks for itself) or every stage is bracketed on its own (full profile).
-        // (Across the chain0 hop from octave 0 to 1 the consumer waits for ev_pyr[0], recorded after these launches.)
         float *half = nullptr;
         if (p->opt.fused_shrink && p->profile <= 1 && oct + 1 < p->n_oct && oct + 1 != tail_first)
             half = p->plane(oct + 1, 0);
-        if (p->profile == 1) {
-            if (oct == 0 && !p->chain) {          // no initial blur: the bracket opens here, five launches
-                Scope *ch = new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0);
-                if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
-                p->chain = ch;
-            }
-            for (int s = 0; s < 5; s++) {
+        if (p->profile == 1 && oct == 0 && !p->chain) {          // no initial blur: the bracket opens here, five launches
+            Scope *ch = new Scope(p, "Blur octave 0, scales 0-4 (one bracket)", true, 5.0 * W * H, nullptr, 0);
+            if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
+            p->chain = ch;
+        }
+        for (int s = 0; s < 5; s++) {
+            if (p->profile > 1) snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
+            {
+                Scope sc(p, lab, true, (double)W * H, pyr, p->profile > 1 ? oct : -2);      // (light profile: octave 0 is inside the open bracket, the others are not timed)
                 if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
-                if (s == 2 && oct == 0 && early0) HIPCHK(hipEventRecord(p->ev_p3, pyr));     // plane 3 (and the hand-off) exist
             }
-            if (oct == 0) {
-                Scope *ch = static_cast<Scope *>(p->chain);
-                const size_t idx = ch ? ch->idx : (size_t)-1;
-                delete ch; p->chain = nullptr;                  // records the bracket's closing event on `pyr`
-                if (idx != (size_t)-1 && two) pyr0_done = p->events[idx].b;   // ... which is also "octave 0's pyramid exists"
-            }
-        } else {
-            for (int s = 0; s < 5; s++) {
-                snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
-                {
-                    Scope sc(p, lab, true, (double)W * H, pyr, oct);
-                    if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
-                }
-                if (s == 2 && oct == 0 && early0) HIPCHK(hipEventRecord(p->ev_p3, pyr));
+            if (s == 2 && oct == 0 && split0) {
+                // plane 3 exists: scale 1 of octave 0 starts on stream2 (the record is a marker packet between two blurs)
+                HIPCHK(hipEventRecord(p->ev_p3, pyr));
+                HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_p3, 0));
+                launch_detect_octave(p, 0, p->stream2, 1);
+                int rc = launch_describe_group(p, 0, p->stream2, slot++);
+                if (rc) return rc;
             }
         }
-        if (two && (oct == 0 || pyr != dst) && !(oct == 0 && pyr0_done)) HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
+        if (oct == 0 && p->profile == 1) {
+            Scope *ch = static_cast<Scope *>(p->chain);
+            const size_t idx = ch ? ch->idx : (size_t)-1;
+            delete ch; p->chain = nullptr;                  // records the bracket's closing event on `pyr`
+            if (idx != (size_t)-1 && two) pyr0_done = p->events[idx].b;   // ... which is also "octave 0's pyramid exists"
+        }
+        if (two && oct == 0 && !pyr0_done) HIPCHK(hipEventRecord(p->ev_pyr[0], pyr));
         return SIFTMI_OK;
     };
-    for (int oct = 0; oct < p->n_oct; oct++) {
-        hipStream_t pyr = pyramid_stream(oct), dst = detect_stream(oct);
-        if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp), then the group's descriptors
-            hipStream_t ts = two ? p->stream3 : p->stream;        // the tail builds pyramids too: it stays on the pyramid chain
-            if (chain0 && oct == 1) HIPCHK(hipStreamWaitEvent(pyr, pyr0_done ? pyr0_done : p->ev_pyr[0], 0));
+    auto wait_pyr0 = [&](hipStream_t st) { return hipStreamWaitEvent(st, pyr0_done ? pyr0_done : p->ev_pyr[0], 0); };
+    int rc = SIFTMI_OK;
+    if (p->n_oct > 0) {
+        // ---- octave 0 (tail_first_octave never takes it: the tail launch starts from plane 3 of an octave above)
+        if ((rc = build_pyramid(0, p->stream))) return rc;
+        if (p->maps_g0) {
+            // octave 0's maps: on the idle stream beside detection and refinement (two streams), else in line
             if (two) {
-                if (pyr != ts) {
-                    HIPCHK(hipEventRecord(p->ev_pyr[(size_t)oct], pyr));
-                    HIPCHK(hipStreamWaitEvent(ts, p->ev_pyr[(size_t)oct], 0));
-                }
-                if (!p->fused && (oct == 1 || split)) HIPCHK(hipStreamWaitEvent(ts, p->ev_mark0, 0));
-            }
-            int rc = launch_tail(p, oct, ts);
-            if (rc) return rc;
-            if (split && oct > 1) {                               // detections of octaves 1 .. oct-1 on stream2
-                HIPCHK(hipEventRecord(p->ev_det, p->stream2));
-                HIPCHK(hipStreamWaitEvent(ts, p->ev_det, 0));
-            }
-            if (p->maps_g1) launch_gradient_maps(p, tail_first == 0 ? 0 : 1, p->n_oct, ts);
-            launch_describe_group(p, later, ts);
-            if (two) HIPCHK(hipEventRecord(p->ev_grp1, ts));
-            break;
-        }
-        int rc = build_pyramid(oct);
-        if (rc) return rc;
-        if (oct == 0 && p->maps_g0) {
-            // octave 0's maps: on the idle stream beside detection and refinement (two-chain layout), else in line
-            if (two) {
-                HIPCHK(hipStreamWaitEvent(p->stream2, pyr0_done ? pyr0_done : p->ev_pyr[0], 0));
+                HIPCHK(wait_pyr0(p->stream2));
                 launch_gradient_maps(p, 0, 1, p->stream2);
                 HIPCHK(hipEventRecord(p->ev_maps0, p->stream2));
             } else launch_gradient_maps(p, 0, 1, p->stream);
         }
-        // Option "early_pyr": octave 1's pyramid is enqueued before octave 0's detection and description (it needs only
-        // ev_pyr[0]).  Off by default: the host is not what delays that chain.
-        if (oct == 0 && chain0 && p->opt.early_pyr && p->n_oct > 1 && tail_first != 1 && (rc = build_pyramid(1))) return rc;
-        if (two) {
-            if (oct == 1 && !p->fused) HIPCHK(hipStreamWaitEvent(dst, p->ev_mark0, 0));
-            if (pyr != dst) HIPCHK(hipStreamWaitEvent(dst, (oct == 0 && pyr0_done) ? pyr0_done : p->ev_pyr[(size_t)oct], 0));
-        }
-#ifdef SIFT_DEV_VARIANTS
-        if (oct == 0 && nbands) {
-            for (int b = 0; b < nbands; b++) {
-                launch_detect_octave(p, 0, p->stream, b, nbands);
-                HIPCHK(hipEventRecord(p->ev_kp[(size_t)b], p->stream));
-                HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_kp[(size_t)b], 0));
-                launch_orient_group(p, b, p->stream2, true);
-                HIPCHK(hipEventRecord(p->ev_out[(size_t)b], p->stream2));
-                HIPCHK(hipStreamWaitEvent(p->stream4, p->ev_out[(size_t)b], 0));
-                launch_descriptor_group(p, b, p->stream4);
+        launch_detect_octave(p, 0, p->stream, split0 ? 2 : 0);
+        // octave 0's gradient maps ran beside detection and refinement: only orientation and description read them
+        if (p->maps_g0 && two) HIPCHK(hipStreamWaitEvent(p->stream, p->ev_maps0, 0));
+        if ((rc = launch_describe_group(p, split0 ? 1 : 0, p->stream, slot++))) return rc;
+    }
+    if (p->n_oct > 1) {
+        // ---- the later octaves: group 2
+        if (two) HIPCHK(wait_pyr0(later));
+        for (int oct = 1; oct < p->n_oct; oct++) {
+            if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp)
+                if ((rc = launch_tail(p, oct, later))) return rc;
+                break;
             }
-            HIPCHK(hipEventRecord(p->ev_mark0, p->stream2));     // every range of octave 0 is frozen: the later octaves may append
-            continue;
+            if ((rc = build_pyramid(oct, later))) return rc;
+            launch_detect_octave(p, oct, later);
         }
-#endif
-        launch_detect_octave(p, oct, dst);
-        // octave 0's gradient maps ran on the idle stream beside detection and refinement: only orientation and description read them
-        if (oct == 0 && p->maps_g0 && two) HIPCHK(hipStreamWaitEvent(dst, p->ev_maps0, 0));
-        if (oct == 0) launch_describe_group(p, 0, dst, p->overlap ? p->ev_mark0 : nullptr);
-        else if (oct == p->n_oct - 1) {
-            hipStream_t ds = two ? p->stream3 : p->stream;        // group 1 is described (and the image ends) on stream3
-            if (dst != ds) {
-                HIPCHK(hipEventRecord(p->ev_det, dst));
-                HIPCHK(hipStreamWaitEvent(ds, p->ev_det, 0));
-            }
-            if (p->maps_g1) launch_gradient_maps(p, 1, p->n_oct, ds);
-            launch_describe_group(p, later, ds);
-            if (two) HIPCHK(hipEventRecord(p->ev_grp1, ds));
-        }
+        if (p->maps_g1) launch_gradient_maps(p, 1, p->n_oct, later);
+        if ((rc = launch_describe_group(p, 2, later, slot++))) return rc;
     }
     if (p->chain) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }   // no octave closed the light-profile bracket (n_oct == 0)
-    // The image ends on the two chains.  Each reads the counter block back into its own pinned copy right after its
-    // descriptor kernel (the host takes the copy with the larger record count: n_out only grows) -- no rejoin hop.
-    // (Capturing this fork / join into a hipGraph was tried: it replays correctly -- as long as stream3 does not rejoin
-    // through stream2, which crashes hipStreamEndCapture on ROCm 7.2 -- but a graph launch is no faster than the plain
-    // launches: small images are bound by the GPU-side latency of dependent kernels, not by host launch cost.)
-    p->wait_a = p->stream; p->wait_b = nullptr;
-    if (two) {
-        hipStream_t end0 = nbands ? p->stream4 : (chain0 ? p->stream : p->stream2);
-        if (p->profile > 1) hipEventRecord(p->ev_last, end0);
-        HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, end0));
-        p->wait_a = end0;
-        if (p->n_oct > 1) {
-            if (p->profile > 1) hipEventRecord(p->ev_last_b, p->stream3);
-            HIPCHK(hipMemcpyAsync(&p->hb->c2, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream3));
-            p->wait_b = p->stream3;
-        }
-    } else {
-        if (p->profile > 1) hipEventRecord(p->ev_last, p->stream);
-        HIPCHK(hipMemcpyAsync(&p->hb->c, p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream));
+    if (slot == 0) {                           // no octave at all: the counters (min / max) still come back
+        HIPCHK(hipMemcpyAsync(&p->hb->c[0], p->cnt, sizeof(Counters), hipMemcpyDeviceToHost, p->stream));
+        p->wait_s[0] = p->stream;
     }
+    // (Capturing this fork / join into a hipGraph was tried in round 2: it replays correctly, but a graph launch is no faster
+    // than the plain launches: small images are bound by the GPU-side latency of dependent kernels, not by host launch cost.)
     p->fin = p->stream;       // copies of the records are issued here after the wait: ordered before the next image's kernels
     return SIFTMI_OK;
 }
 
 // wait for everything in flight on the plan's streams, ignoring errors (error paths only)
-static void drain_streams(siftmi_plan *p) {
-    for (hipStream_t s : {p->stream, p->stream2, p->stream3, p->stream4})
+void drain_streams(siftmi_plan *p) {
+    for (hipStream_t s : {p->stream, p->stream2, p->stream3})
         if (s) (void)hipStreamSynchronize(s);
+    p->in_flight = false;
+}
+
+// The reference's capacity per octave, enforced after the fact on an image that broke it (rare: reference_overflow): at
+// most kpsize records of each octave stay -- which ones is as arbitrary as in the reference, whose atomic counter decides.
+// Device list compacted in place through a gather into a temporary; a pinned result array of the call is stale afterwards
+// (records_cut: siftmi_plan_keypoints copies the list out again).
+int cap_octaves(siftmi_plan *p, const Counters &c, int64_t *n_io) {
+    std::vector<int32_t> keep;
+    std::vector<int64_t> kept((size_t)SIFT_MAX_OCTAVES, 0);
+    std::vector<int32_t> aux;
+    bool cut = false;
+    // the record blocks in list order
+    std::vector<std::pair<int64_t, int>> blocks;            // (base, group)
+    for (int g = 0; g < SIFT_GROUPS; g++)
+        if ((p->groups_cur >> g) & 1u) blocks.push_back({(int64_t)(c.rec_word[g] & 0x7fffffffu), g});
+    std::sort(blocks.begin(), blocks.end());
+    for (auto &bg : blocks) {
+        const int g = bg.second;
+        const int64_t n = std::min<int64_t>(std::min<int64_t>(c.g_out[g], p->grp[g].cap_out), std::max<int64_t>(0, *n_io - bg.first));
+        if (n <= 0) continue;
+        aux.resize((size_t)n);
+        HIPCHK(hipMemcpy(aux.data(), p->grp[g].oaux, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            const int oct = std::min(std::max(aux[(size_t)i] >> 8, 0), SIFT_MAX_OCTAVES - 1);
+            if (kept[(size_t)oct] < p->kpsize) { kept[(size_t)oct]++; keep.push_back((int32_t)(bg.first + i)); }
+            else cut = true;
+        }
+    }
+    if (!cut) return SIFTMI_OK;
+    const size_t m = keep.size();
+    int32_t *didx = nullptr; KpRecord *tmp = nullptr;
+    if (hipMalloc((void **)&didx, std::max<size_t>(m, 1) * 4) != hipSuccess || hipMalloc((void **)&tmp, std::max<size_t>(m, 1) * sizeof(KpRecord)) != hipSuccess) {
+        if (didx) (void)hipFree(didx);
+        return fail(SIFTMI_ENOMEM, "hipMalloc failed while cutting the record list to the per-octave capacity");
+    }
+    hipError_t e = hipMemcpy(didx, keep.data(), m * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m) {
+        hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)std::min<size_t>((m * 36 + 255) / 256, 65535)), dim3(256), 0, p->stream,
+                           (const KpRecord *)p->records, (const int *)didx, tmp, (int)m);
+        e = hipMemcpyAsync(p->records, tmp, m * sizeof(KpRecord), hipMemcpyDeviceToDevice, p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    }
+    (void)hipFree(didx); (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(SIFTMI_EDEVICE, "cutting the record list: %s", hipGetErrorString(e));
+    *n_io = (int64_t)m;
+    p->records_cut = true;
+    return SIFTMI_OK;
 }
 
 // Wait for the image enqueued last on this plan; returns its record count (records stay on the device).
+// SIFTMI_ETAILRETRY / SIFTMI_EGROW (internal): the image has to be enqueued again (the plan has been adjusted).
 int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     HIPCHK(hipSetDevice(p->device));
     // wait by polling: a blocking hipStreamSynchronize can add wake-up latency to a ~1 ms call
     const bool spin = p->opt.spin != 0;
-    hipStream_t ws[2] = {p->wait_a ? p->wait_a : p->stream, p->wait_b};
-    for (hipStream_t w : ws) {
+    for (hipStream_t w : p->wait_s) {
         if (!w) continue;
         if (spin) {
             hipError_t q;
@@ -1349,14 +1291,27 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         HIPCHK(hipStreamSynchronize(w));
     }
     HIPCHK(hipStreamSynchronize(p->stream));
-    const Counters &hc = (p->wait_b && p->hb->c2.n_out > p->hb->c.n_out) ? p->hb->c2 : p->hb->c;
-    const uint32_t *hmm = hc.mm;
+    p->in_flight = false;
     HIPCHK(hipGetLastError());
+    // The complete copy of the counters: the one taken after every group of the image had reserved its record block
+    // (a group reserves when its descriptor launch starts, i.e. after its orientation launch; the stream that ends last
+    // copied after all of them).
+    const Counters *hcp = nullptr;
+    bool tail_timed_out = false;
+    for (int k = 0; k < 3; k++) {
+        if (!p->wait_s[k]) continue;
+        const Counters &c = p->hb->c[k];
+        tail_timed_out = tail_timed_out || c.tail_timeout;
+        bool complete = true;
+        for (int g = 0; g < SIFT_GROUPS; g++) if (((p->groups_cur >> g) & 1u) && !(c.rec_word[g] & 0x80000000u)) complete = false;
+        if (complete && (!hcp || c.n_rec >= hcp->n_rec)) hcp = &c;
+    }
+    if (!hcp) { drain_streams(p); return fail(SIFTMI_EDEVICE, "no complete copy of the image's counters came back"); }
+    const Counters &hc = *hcp;
     {
         auto dec = [](uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; };
-        p->last_min = dec(hmm[0]); p->last_max = dec(hmm[1]);
+        p->last_min = dec(hc.mm[0]); p->last_max = dec(hc.mm[1]);
     }
-    bool tail_timed_out = p->hb->c.tail_timeout || (p->wait_b && p->hb->c2.tail_timeout);
     if (!tail_timed_out && p->opt.tail_fault > 0 && p->opt.tail) { p->opt.tail_fault--; tail_timed_out = true; }   // injected (option "tail_fault")
     if (tail_timed_out) {
         // a workgroup of octave_tail_kernel stopped waiting for the octave above (k_tail.hpp): this image is incomplete.
@@ -1365,10 +1320,24 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         drain_streams(p);
         return fail(SIFTMI_ETAILRETRY, "octave_tail_kernel timed out waiting for the previous octave; tail launches disabled for this plan");
     }
-    int64_t n = hc.n_out;
-    // the overflow flag may have been raised by either detection stream after the other took its snapshot
-    int ovf = hc.overflow | p->hb->c.overflow | (p->wait_b ? p->hb->c2.overflow : 0);
-    if (n > p->kpsize) { n = p->kpsize; ovf = 1; }
+    {
+        // a list that was cut at its buffer's size: grow it and run the image again (what lies behind the cut was never made)
+        bool grown = false;
+        int rc = grow_lists(p, &hc, &grown);
+        if (rc) return rc;
+        if (grown) return fail(SIFTMI_EGROW, "a keypoint list was grown; the image runs again");
+    }
+    int64_t n = 0;
+    for (int g = 0; g < SIFT_GROUPS; g++) if ((p->groups_cur >> g) & 1u) n += std::min<int64_t>(hc.g_out[g], p->grp[g].cap_out);
+    n = std::min<int64_t>(std::min<int64_t>(n, hc.n_rec), p->cap_rec);
+    // the reference's rule: kpsize entries per octave (see reference_overflow); an image that breaks it is flagged and cut to it
+    int ovf = reference_overflow(p, hc) ? 1 : 0;
+    // (a list that cannot grow any further has been cut: only an image beyond that rule gets there)
+    for (int g = 0; g < SIFT_GROUPS; g++)
+        if (((p->groups_cur >> g) & 1u) && (hc.g_kp[g] > p->grp[g].cap_kp || hc.g_out[g] > p->grp[g].cap_out)) ovf = 1;
+    if (hc.n_rec > p->cap_rec) ovf = 1;
+    p->records_cut = false;
+    if (ovf) { int rc = cap_octaves(p, hc, &n); if (rc) return rc; }
     if (p->profile == 1) {                   // light profile: running totals, read once by the caller's benchmark loop
         float tot = 0, bms = 0; int32_t bl = 0; double px = 0;
         if (siftmi_plan_last_kernel_ms(p, &tot, nullptr, nullptr, nullptr) == SIFTMI_OK && siftmi_plan_blur_ms(p, 0, &bms, &bl, &px) == SIFTMI_OK) {
@@ -1376,11 +1345,28 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         }
     }
     p->last_count = n;
-    p->last_group0 = p->fused ? p->hb->c.grp_made[0] : hc.grp_out_end[p->bands_last ? p->bands_last - 1 : 0] - hc.grp_out_start[0];
+    p->last_overflow = ovf;
+    p->last_group0 = (int)std::min<int64_t>((int64_t)hc.g_out[0] + (p->split_cur ? hc.g_out[1] : 0), n);
     p->last_group1 = (int)n - p->last_group0;
     *n_out = n;
     if (overflow) *overflow = ovf;
     return SIFTMI_OK;
+}
+
+// One image, start to finish: enqueue + wait, run again when the plan had to be adjusted under it -- once after a tail
+// time-out (plan_wait has switched to the per-octave launches), and after every growth of a list (at most one per list
+// stage: candidates, refined, oriented, records; what lies behind a cut list only shows once the list is whole).
+int plan_run(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t image_is_device, bool sync_device, int64_t *n, int32_t *ovf) {
+    int rc = SIFTMI_OK, tail_retries = 0;
+    for (int attempt = 0; attempt < 12; attempt++) {
+        rc = plan_enqueue(p, image, image_dtype, image_is_device, sync_device);
+        if (!rc) rc = plan_wait(p, n, ovf);
+        if (rc == SIFTMI_ETAILRETRY && tail_retries++ == 0) continue;
+        if (rc == SIFTMI_EGROW) continue;
+        break;
+    }
+    if (rc == SIFTMI_ETAILRETRY || rc == SIFTMI_EGROW) rc = SIFTMI_EDEVICE;
+    return rc;
 }
 }  // namespace
 
@@ -1398,15 +1384,9 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
     const bool pinned = out_is_device == SIFTMI_OUT_PINNED && out && capacity > 0;
     p->host_out = pinned ? reinterpret_cast<KpRecord *>(out) : nullptr;
     p->host_cap = pinned ? (int)(capacity < 0x7fffffff ? capacity : 0x7fffffff) : 0;
-    int rc = plan_enqueue(p, image, image_dtype, image_is_device, true);
     int64_t n = 0;
     int32_t ovf = 0;
-    if (!rc) rc = plan_wait(p, &n, &ovf);
-    if (rc == SIFTMI_ETAILRETRY) {           // once: plan_wait has switched the plan to the per-octave launches
-        rc = plan_enqueue(p, image, image_dtype, image_is_device, true);
-        if (!rc) rc = plan_wait(p, &n, &ovf);
-        if (rc == SIFTMI_ETAILRETRY) rc = SIFTMI_EDEVICE;
-    }
+    int rc = plan_run(p, image, image_dtype, image_is_device, true, &n, &ovf);
     p->host_out = nullptr; p->host_cap = 0;
     if (rc) {
         // descriptor kernels that were already launched may still be writing to the caller's pinned block: nothing
@@ -1419,7 +1399,8 @@ int siftmi_plan_keypoints(siftmi_plan *p, const void *image, int32_t image_dtype
         // count-only call: the records stay on the device until siftmi_plan_fetch()
     } else {
         if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "output capacity too small; result truncated"; }
-        if (n > 0 && !pinned) {
+        // (pinned: the kernels have written the records already -- unless the list was cut to the per-octave capacity afterwards)
+        if (n > 0 && (!pinned || p->records_cut)) {
             HIPCHK(hipMemcpyAsync(out, p->records, (size_t)n * sizeof(KpRecord),
                                   out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, fin));
             HIPCHK(hipStreamSynchronize(fin));
@@ -1617,17 +1598,17 @@ int batch_retire(siftmi_batch *b, size_t l, int32_t *overflow) {
     if (img >= b->batch_size) { b->lane_image[l] = -1; return fail(SIFTMI_EINVAL, "stale frame index %d on lane %zu", img, l); }
     int64_t n = 0; int32_t ovf = 0;
     int rc = plan_wait(p, &n, &ovf);
-    if (rc == SIFTMI_ETAILRETRY && b->cur_images) {
-        // a workgroup of octave_tail_kernel gave up waiting (k_tail.hpp: most likely queued behind another lane's persistent
-        // descriptor workgroups -- a batch-only condition).  plan_wait has drained the lane and switched it to the per-octave
-        // launches: the frame runs once more on the same lane, as siftmi_plan_keypoints does for a single plan.
-        b->tail_retries++;
+    if ((rc == SIFTMI_ETAILRETRY || rc == SIFTMI_EGROW) && b->cur_images) {
+        // A workgroup of octave_tail_kernel gave up waiting (k_tail.hpp: most likely queued behind another lane's persistent
+        // descriptor workgroups -- a batch-only condition) and plan_wait has switched the lane to the per-octave launches, or
+        // the frame outran a list of the lane and plan_wait has grown it: the frame runs again on the same lane, as
+        // siftmi_plan_keypoints does for a single plan (plan_run).
+        if (rc == SIFTMI_ETAILRETRY) b->tail_retries++;
         // (a host frame is still in its ring slot: the slot is not reused before its frame has retired)
         const bool staged = !b->cur_is_device && !b->ring.empty();
-        rc = plan_enqueue(p, staged ? b->ring[(size_t)img % b->ring.size()] : b->cur_images[img], b->cur_dtype, staged ? 1 : b->cur_is_device, false);
-        if (!rc) rc = plan_wait(p, &n, &ovf);
+        rc = plan_run(p, staged ? b->ring[(size_t)img % b->ring.size()] : b->cur_images[img], b->cur_dtype, staged ? 1 : b->cur_is_device, false, &n, &ovf);
     }
-    if (rc == SIFTMI_ETAILRETRY) rc = fail(SIFTMI_EDEVICE, "octave_tail_kernel timed out twice on frame %d", img);
+    if (rc == SIFTMI_ETAILRETRY || rc == SIFTMI_EGROW) rc = fail(SIFTMI_EDEVICE, "frame %d could not be completed after its plan was adjusted", img);
     if (rc) return rc;
     if (ovf && overflow) *overflow = 1;
     if (p->profile) {
@@ -1683,8 +1664,7 @@ void batch_drain(siftmi_batch *b) {
         if (b->lane_image[l] < 0) continue;
         siftmi_plan *p = b->lanes[l];
         if (hipSetDevice(p->device) == hipSuccess) {
-            for (hipStream_t s : {p->stream, p->stream2, p->stream3, p->stream4})
-                if (s) (void)hipStreamSynchronize(s);
+            drain_streams(p);
         }
         b->lane_image[l] = -1;
     }
@@ -1890,10 +1870,9 @@ int siftmi_plan_last_kernel_ms(const siftmi_plan *p, float *total_ms, float *blu
     if (!p->profile) return fail(SIFTMI_EINVAL, "plan was created with profile=0");
     float tot = 0;                            // light profile: not measured (0)
     if (p->profile > 1) {
-        HIPCHK(hipEventElapsedTime(&tot, p->ev_first, p->ev_last));
-        if (p->wait_b) {
+        for (int k = 0; k < 3; k++) {
             float tb = 0;
-            if (hipEventElapsedTime(&tb, p->ev_first, p->ev_last_b) == hipSuccess && tb > tot) tot = tb;
+            if (p->wait_s[k] && hipEventElapsedTime(&tb, p->ev_first, p->ev_last[k]) == hipSuccess && tb > tot) tot = tb;
         }
     }
     if (total_ms) *total_ms = tot;
@@ -2280,10 +2259,10 @@ int siftmi_stage_interp(int32_t dev, const float *blurs, int32_t W, int32_t H, c
     Counters *dc = cnt.as<Counters>();
     hipLaunchKernelGGL(refine_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, 0, bp, W, H, (const float4 *)c.as<float4>(),
                        (const int *)&dc->n_cand[0], (int)n, par->peak_thresh, (float)par->init_sigma, k.as<float4>(),
-                       ks.as<int>(), &dc->n_kp, (int)n, 0, (int *)nullptr, (const int *)nullptr);
+                       ks.as<int>(), &dc->g_kp[0], (int)n, 0, &dc->c_scale[0][0]);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
-    const int64_t m = hc.n_kp;
+    const int64_t m = hc.g_kp[0];
     if (m > 0) {
         HIPCHK(hipMemcpy(out, k.p, (size_t)m * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out_scale, ks.p, (size_t)m * 4, hipMemcpyDeviceToHost));
@@ -2335,7 +2314,7 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     if ((rc = b.upload(blurs, 6 * N * 4)) || (rc = k.upload(kps, (size_t)n * 16)) || (rc = ks.upload(kp_scale, (size_t)n * 4)) ||
         (rc = o.alloc((size_t)capacity * 16)) || (rc = oa.alloc((size_t)capacity * 4)) || (rc = cnt.alloc(sizeof(Counters)))) return rc;
     Counters hc{};
-    hc.n_kp = (int)n;
+    hc.g_kp[0] = (int)n;
     HIPCHK(hipMemcpy(cnt.p, &hc, sizeof hc, hipMemcpyHostToDevice));
     int oct = 0;
     while ((1 << oct) < octsize && oct < SIFT_MAX_OCTAVES - 1) oct++;
@@ -2348,10 +2327,10 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(orientation_kernel<false>, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
                        par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
-                       o.as<float4>(), oa.as<int>(), (int)capacity, 0, 0, 512);
+                       o.as<float4>(), oa.as<int>(), (int *)nullptr, (int)capacity, 0, 512);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
-    int64_t m = hc.n_out < capacity ? hc.n_out : capacity;
+    int64_t m = hc.g_out[0] < capacity ? hc.g_out[0] : capacity;
     if (m > 0) {
         HIPCHK(hipMemcpy(out, o.p, (size_t)m * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out_scale, oa.p, (size_t)m * 4, hipMemcpyDeviceToHost));
@@ -2386,12 +2365,12 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
         }
         if (block_ok)
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
-                               (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30, (const int *)nullptr);
+                               (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (Counters *)nullptr, 0, 0, (int)n,
+                               (int)n, r.as<KpRecord>(), (int)n, (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30, (const int *)nullptr, 0);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
-                               (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (const Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>(), (KpRecord *)nullptr, 0);
+                               (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (Counters *)nullptr, 0, 0, (int)n,
+                               (int)n, r.as<KpRecord>(), (int)n, (KpRecord *)nullptr, 0);
     }
     if ((rc = stage_end())) return rc;
     std::vector<KpRecord> h((size_t)n);

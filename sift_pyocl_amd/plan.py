@@ -320,7 +320,7 @@ class SiftPlan(object):
                 output = output[:count]
             self.overflow = bool(ovf.value)
             if self.overflow:
-                logger.warning("Keypoint counter overflow: more than %s keypoints, result truncated", self.kpsize)
+                logger.warning("Keypoint counter overflow: an octave needs more than %s entries, result cut to that per octave", self.kpsize)
             output = output.view(numpy.recarray)
             del keep
             if logger.isEnabledFor(logging.INFO):
@@ -333,6 +333,13 @@ class SiftPlan(object):
         """Tuning / diagnostic option of the device plan by name (``siftmi_plan_set_option`` in include/siftmi.h);
         results never depend on an option."""
         _lib.check(_lib.lib().siftmi_plan_set_option(self._handle, str(name).encode(), int(value)))
+
+    def capacity(self):
+        """(records the device list holds now, times a list has grown).  The lists start at ``kpsize`` entries -- the
+        reference's capacity per octave (plan.py:243, 797-804) -- and grow when an image within that rule needs more."""
+        rec, grows = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().siftmi_plan_capacity(self._handle, C.byref(rec), C.byref(grows)))
+        return int(rec.value), int(grows.value)
 
     def device_records(self):
         """The records of the last keypoints() call where they lie on the device (no copy): an object with

@@ -76,11 +76,10 @@ def test_2048_keypoint_rich_bit_exact(siftlib, oracle):
     assert len(got) > 30000
     want = oracle.keypoints(img)
     assert_same_keypoints(got, want, "2048 smoothed noise")
-    # launch-layout options that only large frames reach (none may change a byte): detection on its own stream, the early
-    # enqueue of octave 1's pyramid, the round-1 stream layout -- each with the lazy gradient and with full maps.  (The band
-    # pipeline of octave 0 and the early start of the later octaves' chain, both measured slower, exist in development
-    # builds only since round 4: SIFT_DEV_VARIANTS.)
-    for opts in (dict(split_detect=1), dict(early_pyr=1), dict(chain0=0)):
+    # launch-layout options that only large frames reach (none may change a byte): octave 0 as one group instead of two
+    # (scale 1 / scales 2-3), list-order hand-out in the descriptor launch, one stream -- each with the lazy gradient and
+    # with full maps
+    for opts in (dict(split0=0), dict(desc_bucket=0), dict(overlap=0), dict(split0=0, desc_bucket=0)):
         for maps in (0, 1):
             p2 = sp.SiftPlan(template=img)
             p2.set_option("maps", maps)
@@ -101,9 +100,9 @@ def test_odd_sizes_and_borders(siftlib, oracle):
 def test_capacity_overflow_is_reported(siftlib):
     import sift_pyocl_amd as sp
     img = smooth_noise((512, 512))
-    plan = sp.SiftPlan(template=img, PIX_PER_KP=1000)      # kpsize 262 << ~2400 keypoints
+    plan = sp.SiftPlan(template=img, PIX_PER_KP=1000)      # kpsize 262 per octave << ~1950 keypoints in octave 0
     got = plan.keypoints(img)
-    assert plan.overflow and len(got) <= plan.kpsize
+    assert plan.overflow and len(got) <= plan.octave_max * plan.kpsize      # (tests/test_gpu_capacity.py has the rule in full)
 
 
 def test_match_100k_against_the_full_oracle(siftlib, oracle):

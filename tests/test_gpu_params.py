@@ -91,14 +91,11 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
     assert_same_keypoints(plan.keypoints(img), want, "gradient maps, one stream")
     plan.set_option("overlap", 1)
     plan.set_option("maps", 2)
-    # the descriptor launch in list order / largest windows first whatever the density ("desc_sort", "desc_sort_density")
-    for sort, density in ((0, 600), (16384, 1)):
-        plan.set_option("desc_sort", sort)
-        plan.set_option("desc_sort_density", density)
+    # the descriptor launch in list order / scale 3 first ("desc_bucket": groups below that many keypoints)
+    for bucket in (0, 1 << 30):
+        plan.set_option("desc_bucket", bucket)
         plan.set_option("desc_team", 0)                          # the wave-per-keypoint form is the one that follows the order
-        assert_same_keypoints(plan.keypoints(img), want, "desc_sort %d" % sort)
-    plan.set_option("desc_sort", 16384)
-    plan.set_option("desc_sort_density", 600)
+        assert_same_keypoints(plan.keypoints(img), want, "desc_bucket %d" % bucket)
     plan.set_option("desc_team", 1024)
     plan.pinned_results = False                                  # plain numpy result + device-to-host copy
     assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
@@ -176,9 +173,9 @@ def test_small_frame_kernels_agree(siftlib, oracle, shape):
     assert len(base) > 5
     if want is not None:
         assert_same_keypoints(base, want, "defaults vs oracle %r" % (shape,))
-    for opts in (dict(tail=0), dict(tail=0, tile=1, ext_rows=32), dict(tail=1, tile=2, ext_rows=8), dict(tail=1, overlap=0),
-                 dict(split_detect=1, early_pyr=1), dict(desc_team=0), dict(desc_team=1 << 30, chain0=0),
-                 dict(desc_team=0, desc_dynamic=0, desc_blocks=333), dict(desc_team=0, desc_blocks=7, ori_blocks=77), dict(ori_team=0), dict(ori_team=1 << 30, ori_blocks=5), dict(fused_shrink=0), dict(fused_shrink=1, chain0=0, tail=0), dict(fused_refine=0), dict(fused_refine=2, tail=0)):
+    for opts in (dict(tail=0), dict(tail=0, ext_rows=32), dict(tail=1, ext_rows=8), dict(tail=1, overlap=0),
+                 dict(desc_bucket=0), dict(desc_team=0), dict(desc_team=1 << 30, split0=0),
+                 dict(desc_team=0, desc_dynamic=0, desc_blocks=333), dict(desc_team=0, desc_blocks=7, ori_blocks=77), dict(ori_team=0), dict(ori_team=1 << 30, ori_blocks=5), dict(fused_shrink=0), dict(fused_shrink=1, overlap=0, tail=0), dict(fused_refine=0), dict(fused_refine=2, tail=0)):
         other = sp.SiftPlan(template=img)
         for name, value in opts.items():
             other.set_option(name, value)

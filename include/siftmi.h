@@ -99,7 +99,7 @@ int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
  *                      keypoints are described detection scale 3 first; 0: list order), "desc_stream", "maps_blocks"
  *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",
  *                      "maps" (0 never / 1 always / 2 by the previous image's count), "maps_density"
- *   stream schedule    "overlap" (0: one stream), "split0" (octave 0 of a large frame in two groups: scale 1 from plane 3 on), "spin"
+ *   stream schedule    "overlap" (0: one stream), "fork" (the octaves below octave 0 as two chains and groups -- octave 1 | the rest: 0 never, 1 always, 2 from five octaves), "spin"
  *   diagnostics        "host_timing", "tail_fault" (treat the next n tail launches as timed out: exercises the re-run path) */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 /* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from

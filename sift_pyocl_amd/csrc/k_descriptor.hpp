@@ -536,8 +536,6 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
             t_hi = __shfl(cand, i_hi);
             t_lo = -__shfl(cand, i_lo);
         }
-        auto below_hi = [&](float u) { return thr_ok ? (u < t_hi) : (g(u) < 4.0f); };
-        auto above_lo = [&](float u) { return thr_ok ? (u > t_lo) : (g(u) > -1.0f); };
         w.fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;      // no under / overflow in div_by_reciprocal
 
         PH_COUNT(13);
@@ -814,8 +812,6 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
             t_hi = __shfl(cand, i_hi);
             t_lo = -__shfl(cand, i_lo);
         }
-        auto below_hi = [&](float u) { return thr_ok ? (u < t_hi) : (g(u) < 4.0f); };
-        auto above_lo = [&](float u) { return thr_ok ? (u > t_lo) : (g(u) > -1.0f); };
         w.fast_div = thr_ok && spacing >= 0.1f && spacing <= 128.0f;
 
         // ---- 1b. row intervals: thread t owns window row t (S <= 255)

@@ -114,9 +114,7 @@ __device__ __forceinline__ void ext_edge_filter(const BlurPlanes &b, int W, floa
 // caller's to flush.
 // REFINE: the survivors of the edge test are refined and appended to the keypoint list right here, one parked entry per
 // lane (no candidate list, no refinement launch); nothing is left parked on return.
-// S0, NS: the detection scales [S0, S0 + NS) of the octave are tested (planes S0 - 1 .. S0 + NS + 1 are read): all three in one
-// pass, or -- octave 0 of a large frame, whose scale 1 is detected as soon as plane 3 exists -- scale 1 and scales 2-3 apart.
-template <int BUF, bool REFINE = false, int S0 = 1, int NS = 3>
+template <int BUF, bool REFINE = false>
 __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H, int border, int rows, bool active, int sx, int sy,
                                               double contrast, float edth, float4 *__restrict__ cand, int *__restrict__ counter,
                                               int capacity, ExtWaveLdsT<BUF> &L, int &pending, const RefineArgs *ra = nullptr,
@@ -150,43 +148,40 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
     auto from_left = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); };    // wave_shr:1
     auto from_right = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); };   // wave_shl:1
 
-    constexpr int NP = NS + 3, P0 = S0 - 1;   // planes read: P0 .. P0 + NP - 1 (NS + 2 DoG planes)
-    float hM[3][NS], hm[3][NS];   // [row slot][scale]: horizontal+scale max / min for rows y-2, y-1, y
-    float ctr[NS], ctr_next[NS];
-#pragma unroll
-    for (int k = 0; k < NS; k++) ctr[k] = 0.f;
+    float hM[3][3], hm[3][3];   // [row slot][scale]: horizontal+scale max / min for rows y-2, y-1, y
+    float ctr[3] = {0.f, 0.f, 0.f}, ctr_next[3];
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int k = 0; k < NS; k++) { hM[r][k] = 0.f; hm[r][k] = 0.f; }
+        for (int k = 0; k < 3; k++) { hM[r][k] = 0.f; hm[r][k] = 0.f; }
 
     const unsigned pitch = (unsigned)W * 4u;
     unsigned off = ((unsigned)max(ya - 1, 0) * (unsigned)W + (unsigned)xc) * 4u;   // byte offset of the row being loaded
-    float vn[NP];                                    // next row's samples, loaded one iteration ahead
+    float vn[6];                                     // next row's samples, loaded one iteration ahead
     if (active) {
 #pragma unroll
-        for (int k = 0; k < NP; k++) vn[k] = ld(P0 + k, off);
+        for (int k = 0; k < 6; k++) vn[k] = ld(k, off);
     } else {
 #pragma unroll
-        for (int k = 0; k < NP; k++) vn[k] = 0.f;
+        for (int k = 0; k < 6; k++) vn[k] = 0.f;
     }
     for (int y = ya - 1; y <= yb; y++) {
-        float v[NP];
+        float v[6];
 #pragma unroll
-        for (int k = 0; k < NP; k++) v[k] = vn[k];
+        for (int k = 0; k < 6; k++) v[k] = vn[k];
         if (y < yb) {
             off += pitch;
 #pragma unroll
-            for (int k = 0; k < NP; k++) vn[k] = ld(P0 + k, off);
+            for (int k = 0; k < 6; k++) vn[k] = ld(k, off);
         }
-        float d[NP - 1];
+        float d[5];
 #pragma unroll
-        for (int k = 0; k < NP - 1; k++) d[k] = v[k] - v[k + 1];
+        for (int k = 0; k < 5; k++) d[k] = v[k] - v[k + 1];
         // shift rolling window
 #pragma unroll
-        for (int k = 0; k < NS; k++) { hM[0][k] = hM[1][k]; hM[1][k] = hM[2][k]; hm[0][k] = hm[1][k]; hm[1][k] = hm[2][k]; }
+        for (int k = 0; k < 3; k++) { hM[0][k] = hM[1][k]; hM[1][k] = hM[2][k]; hm[0][k] = hm[1][k]; hm[1][k] = hm[2][k]; }
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
+        for (int k = 0; k < 3; k++) {
             const float M = fmaxf(fmaxf(d[k], d[k + 1]), d[k + 2]);
             const float m = fminf(fminf(d[k], d[k + 1]), d[k + 2]);
             hM[2][k] = fmaxf(fmaxf(from_left(M), M), from_right(M));
@@ -194,13 +189,11 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
             ctr_next[k] = d[k + 1];
         }
         // centre row is y-1; it is complete once rows y-2, y-1, y have been seen
-        bool found[NS];
-#pragma unroll
-        for (int k = 0; k < NS; k++) found[k] = false;
+        bool found[3] = {false, false, false};
         const int yc = y - 1;
         if (y >= ya + 1 && col_ok) {
 #pragma unroll
-            for (int k = 0; k < NS; k++) {
+            for (int k = 0; k < 3; k++) {
                 const float val = ctr[k];
                 if (fabsf(val) >= cf) {
                     const float M27 = fmaxf(fmaxf(hM[0][k], hM[1][k]), hM[2][k]);
@@ -211,10 +204,10 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
         }
         // park this row's candidates (ballot compaction: no atomics)
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
+        for (int k = 0; k < 3; k++) {
             const unsigned long long m = __ballot(found[k]);
             if (m) {                                                  // wave uniform
-                if (found[k]) L.buf[pending + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(ctr[k], (float)yc, (float)x, (float)(k + S0));
+                if (found[k]) L.buf[pending + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(ctr[k], (float)yc, (float)x, (float)(k + 1));
                 pending += __popcll(m);
             }
         }
@@ -230,7 +223,7 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
             }
         }
 #pragma unroll
-        for (int k = 0; k < NS; k++) ctr[k] = ctr_next[k];
+        for (int k = 0; k < 3; k++) ctr[k] = ctr_next[k];
     }
     ext_edge_filter(b, W, edth, L, tested, pending, lane);
     if (REFINE) refine_parked();
@@ -238,7 +231,7 @@ __device__ __forceinline__ void extrema_strip(const BlurPlanes &b, int W, int H,
 
 // (the fused-refinement form is the one of small planes, a latency chain of few workgroups: it takes the registers it
 // needs -- at the five-wave budget it spilled four to scratch)
-template <bool REFINE, int S0 = 1, int NS = 3>
+template <bool REFINE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REFINE ? 4 : SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
                                                       float edth, float4 *__restrict__ cand,
                                                       int *__restrict__ counter, int capacity, RefineArgs ra,
@@ -253,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REFINE ? 4 
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
     int pending = 0;                                     // candidates parked in L.buf (wave uniform)
-    extrema_strip<SIFT_EXT_BUF, REFINE, S0, NS>(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand,
+    extrema_strip<SIFT_EXT_BUF, REFINE>(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand,
                                         counter, capacity, L, pending, &ra, y_lo, y_hi);
     if (REFINE) return;                                  // every survivor is already in the keypoint list
     // ---- what is left leaves with one atomicAdd per workgroup

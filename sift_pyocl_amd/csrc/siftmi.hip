@@ -125,8 +125,12 @@ struct Options {
                              // 1024^2 smoothed 0.588 / 0.568 / 0.568 / 0.570 ms, 2048^2 white 0.500 / 0.499 / 0.520 / 0.521, headline and the other frames equal
     int desc_bucket = 1 << 30;   // groups of fewer oriented keypoints than this are handed out scale 3 first in the wave form of the
                              // descriptor launch (the three hand-out lists the orientation launch fills; 0: list order) -- see k_descriptor.hpp
-    int split0 = 0;          // octave 0 of a large frame in two groups: detection scale 1 (planes 0-3) is detected, oriented and described on
-                             // `stream2` from the moment plane 3 exists, under the last two blurs of the octave; scales 2-3 follow on `stream`
+    int fork = 2;            // the later octaves in two chains: octave 1 (detection to description, group 1) on `stream3`, the octaves below it
+                             // (pyramids from octave 1's plane 3 on, the tail launch, group 2) on `stream2`.  0: one chain, one group; 1: always;
+                             // 2: frames of at least five octaves.  Interleaved A/B, forked against one chain (white noise unless noted): 512^2
+                             // 0.205 / 0.249 ms, 1024^2 0.281 / 0.328, 2048^2 0.450 / 0.508, 4096^2 with 9 / 5 / 4 / 3 octaves 0.943 / 0.956,
+                             // 0.852 / 0.868, 0.830 / 0.833, 0.821 / 0.789 (three octaves: two sparse groups each pay a launch chain beside
+                             // octave 0's descriptors), 16384^2 10.46 / 10.48; smoothed noise 4096^2 4.45 / 4.38, 2048^2 1.45 / 1.49
     int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
     int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)
     int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
@@ -182,12 +186,13 @@ struct siftmi_plan {
     int64_t bytes = 0;
     float *planes = nullptr;      // all octaves' blur planes: octave o, scale s at plane(o, s)
     std::vector<size_t> oct_off;  // float offset of octave o's first plane
-    float *tmp = nullptr;         // generic blur only
-    hipStream_t stream2 = nullptr;            // scale 1 of a split octave 0 (detection to description); octave 0's gradient maps
-    hipStream_t stream3 = nullptr;            // the later octaves: pyramids, detection, description
+    float *tmp = nullptr;         // generic two-pass blur only (tap counts without a fused kernel): intermediate plane
+    float *tmp_below = nullptr;   // ... of the chain of the octaves below octave 1, which runs beside octave 1's last blurs
+    hipStream_t stream2 = nullptr;            // octave 0's gradient maps; the octaves below octave 1 (pyramids, detection, the tail launch, description)
+    hipStream_t stream3 = nullptr;            // octave 1 (pyramid, detection, description) -- or every later octave when they form one chain
     int64_t acc_calls = 0, acc_b0_launches = 0;   // running totals of the light profile (siftmi_plan_profile_totals)
     double acc_total_ms = 0, acc_b0_ms = 0, acc_b0_pixels = 0;
-    hipEvent_t ev_p3 = nullptr;               // plane 3 of octave 0 exists (split octave 0: stream2 starts there)
+    hipEvent_t ev_p3 = nullptr;               // plane 3 of octave 1 (and octave 2's plane 0) exist: the chain of the octaves below starts there
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
     float *plane(int o, int s) const { return planes + oct_off[(size_t)o] + (size_t)s * (size_t)ow[(size_t)o] * (size_t)oh[(size_t)o]; }
@@ -200,9 +205,9 @@ struct siftmi_plan {
     int last_group1 = 0;          // ... of the later octaves
     float *gmap = nullptr, *omap = nullptr;   // gradient maps (allocated on first use: half the size of `planes` each)
     size_t planes_floats = 0;
-    bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves
+    bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves (groups 1 and 2)
     // the image being enqueued / waited for
-    bool split_cur = false;                   // octave 0 in two groups (0: scale 1, 1: scales 2-3)
+    bool fork_cur = false;                    // octave 1 is a group of its own (1), the octaves below it group 2; else all later octaves in group 2
     unsigned groups_cur = 0;                  // bit g: group g has launches in this image
     int tail_first_cur = 0;                   // first octave of the tail launch (n_oct: none)
     hipEvent_t ev_maps0 = nullptr;
@@ -400,7 +405,7 @@ bool launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, cons
     if (!st) st = p->stream;
     const int r = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm, half)
                        : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm, half);
-    if (!r) launch_blur_generic(st, in, out, p->tmp, W, H, t, p->mm, norm);
+    if (!r) launch_blur_generic(st, in, out, (st == p->stream2 && p->tmp_below) ? p->tmp_below : p->tmp, W, H, t, p->mm, norm);
     return r == 2;
 }
 
@@ -481,6 +486,7 @@ OctaveTable octave_table(const siftmi_plan *p) {
 // and the oriented keypoints of the scale behind those.  An image may therefore return up to kpsize records per octave.
 // Here the lists of a group start at kpsize entries and grow when an image needs more (the image is then run again), up
 // to what that rule can ever admit; `reference_overflow` evaluates the rule itself from the per-scale counts.
+int group_of(const siftmi_plan *p, int oct);
 int64_t list_limit(const siftmi_plan *p, int what, int g) {      // what: 0 candidates, 1 refined, 2 oriented, 3 records
     const int64_t K = p->kpsize, O = std::max(1, p->n_oct);
     int64_t lim = what == 0 ? 3 * K : (what == 1 ? 3 * K * (g == 2 ? O : 1) : (what == 2 ? K * (g == 2 ? O : 1) : K * O));
@@ -495,19 +501,19 @@ int grow_lists(siftmi_plan *p, const Counters *c, bool *grown = nullptr) {
     bool drained = c == nullptr;
     // nothing of the plan may be in flight while a buffer is replaced (another ending stream may still be copying its counters)
     auto quiesce = [&]() { if (!drained) { drain_streams(p); drained = true; } };
-    const bool can_split = p->n_oct > 0 && march_plane(p->ow[0], p->oh[0]);
+    const bool forks = p->n_oct > 2;                    // (group 1 exists only beside a group 2)
     auto want = [&](int64_t cap, int64_t need, int64_t limit) {
         if (need <= cap) return cap;
         if (!c) return std::min<int64_t>(limit, need);                        // creation: exactly the reference's kpsize
         return std::min<int64_t>(limit, std::max<int64_t>(need + need / 4 + 64, cap));
     };
     for (int g = 0; g < SIFT_GROUPS; g++) {
-        if (g == 1 && !can_split) continue;
+        if (g == 1 && !forks) continue;
         GroupLists &G = p->grp[g];
         int64_t need_cand = p->kpsize, need_kp = p->kpsize, need_out = p->kpsize;
         if (c) {
-            need_cand = g == 0 ? c->n_cand[0] : (g == 1 ? c->n_cand[SIFT_MAX_OCTAVES] : 0);
-            if (g == 2) for (int o = 1; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) need_cand = std::max<int64_t>(need_cand, c->n_cand[o]);
+            need_cand = 0;
+            for (int o = 0; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) if (group_of(p, o) == g) need_cand = std::max<int64_t>(need_cand, c->n_cand[o]);
             need_kp = c->g_kp[g]; need_out = c->g_out[g];
         }
         const int64_t cc = want(G.cap_cand, need_cand, list_limit(p, 0, g)), ck = want(G.cap_kp, need_kp, list_limit(p, 1, g)),
@@ -552,17 +558,16 @@ bool reference_overflow(const siftmi_plan *p, const Counters &c) {
     return false;
 }
 
-// Group of an octave: octave 0 alone (group 0; groups 0 and 1 when it is split by scale), every later octave in group 2.
-int group_of(const siftmi_plan *, int oct) { return oct == 0 ? 0 : 2; }
+// Group of an octave in the image being enqueued: octave 0, octave 1, everything below -- or, when the later octaves form
+// one chain (single stream, option "fork" = 0, octave 1 inside the tail launch), octave 0 and everything below it.
+int group_of(const siftmi_plan *p, int oct) { return oct == 0 ? 0 : ((oct == 1 && p->fork_cur) ? 1 : 2); }
 
-// Extrema of the detection scales + sub-pixel refinement of one octave; survivors are appended to the refined list of
-// the octave's group (tagged with the octave).
-// part 0: the three scales in one pass.  Octave 0 split by scale (Options::split0): part 1 = scale 1 (planes 0-3, group 0),
-// part 2 = scales 2-3 (planes 1-5, group 1), each with its own candidate list and counter.
-void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int part = 0) {
+// Extrema of the three detection scales + sub-pixel refinement of one octave; survivors are appended to the refined list
+// of the octave's group (tagged with the octave).
+void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
     const int W = p->ow[(size_t)oct], H = p->oh[(size_t)oct];
     const int octsize = 1 << oct;
-    const int g = part == 2 ? 1 : group_of(p, oct);
+    const int g = group_of(p, oct);
     GroupLists &G = p->grp[g];
     p->groups_cur |= 1u << g;
     char lab[96];
@@ -570,7 +575,7 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int part = 0)
     for (int s = 0; s < 6; s++) bp.p[s] = p->plane(oct, s);
     const int border = p->par.border_dist;
     const int ccap = (int)G.cap_cand, kcap = (int)G.cap_kp;
-    int *n_cand = &p->cnt->n_cand[part == 2 ? SIFT_MAX_OCTAVES : oct];
+    int *n_cand = &p->cnt->n_cand[oct];
     if (!(W > 2 * border && H > 2 * border)) return;
     const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border, p->opt.ext_strips);
     const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
@@ -580,7 +585,7 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int part = 0)
     // One launch detects and refines (the survivors of the edge test are refined by the wave that parked them: no
     // candidate list, no second launch) unless every stage is bracketed on its own (full profile) or option
     // "fused_refine" says otherwise (0: never, 1: planes below 1400^2, 2: every plane).
-    const bool fused = part == 0 && p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
+    const bool fused = p->profile <= 1 && (p->opt.fused_refine == 2 || (p->opt.fused_refine == 1 && !march_plane(W, H)));
     if (fused) {
         snprintf(lab, sizeof lab, "local_maxmin+interp_keypoint %d", oct);
         Scope sc(p, lab, false, 0, st);
@@ -589,20 +594,13 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st, int part = 0)
         return;
     }
     {
-        snprintf(lab, sizeof lab, "local_maxmin %d%s", oct, part == 1 ? " scale 1" : (part == 2 ? " scales 2-3" : ""));
+        snprintf(lab, sizeof lab, "local_maxmin %d", oct);
         Scope sc(p, lab, false, 0, st);
-        if (part == 1)
-            hipLaunchKernelGGL((extrema_kernel<false, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                               contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
-        else if (part == 2)
-            hipLaunchKernelGGL((extrema_kernel<false, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                               contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
-        else
-            hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                               contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
+        hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
+                           contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
     }
     {
-        snprintf(lab, sizeof lab, "interp_keypoint+compact %d%s", oct, part == 1 ? " scale 1" : (part == 2 ? " scales 2-3" : ""));
+        snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)G.cand,
                            (const int *)n_cand, ccap, p->par.peak_thresh, (float)p->par.init_sigma, G.kp,
@@ -659,7 +657,7 @@ int launch_tail(siftmi_plan *p, int first, hipStream_t st) {
             have = lds;
         }
     }
-    GroupLists &G = p->grp[2];                 // the tail's octaves are later octaves (or the whole image): group 2
+    GroupLists &G = p->grp[2];                 // the tail's octaves are the last ones: group 2
     p->groups_cur |= 1u << 2;
     hipLaunchKernelGGL(octave_tail_kernel, dim3((unsigned)a.n), dim3(SIFT_TAIL_THREADS), lds, st, a, p->par.border_dist,
                        contrast_threshold(p->par), p->par.peak_thresh, (float)p->par.init_sigma, p->tail_cand, p->tail_cand_cap,
@@ -675,7 +673,7 @@ void launch_orient_group(siftmi_plan *p, int group, hipStream_t st) {
     snprintf(lab, sizeof lab, "orientation_assignment group %d", group);
     Scope sc(p, lab, false, 0, st);
     const int ori_blocks = p->opt.ori_blocks, ori_pad = p->opt.ori_pad;
-    const bool maps = group < 2 ? p->maps_g0 : p->maps_g1;
+    const bool maps = group == 0 ? p->maps_g0 : p->maps_g1;
     if (maps)
         hipLaunchKernelGGL(orientation_kernel<true>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
                            (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, G.ord, (int)G.cap_out,
@@ -701,12 +699,12 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
     const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
     // a small group of octave 0 of a LARGE frame leaves room for the later octaves' chain, which ends such an image (4096^2
     // headline -2.2 %, 4096^2 with every octave -2.5 %); on a 1024^2 frame that chain is short and the same cut costs 2 %
-    const int small_blocks = (group < 2 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
+    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
     const int ocap = (int)G.cap_out, rcap = (int)std::min<int64_t>(p->cap_rec, 0x7fffffff);
     if (p->desc_rows && !p->opt.desc_stream) {
         // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
         // (throughput) or the workgroup-per-keypoint form (latency of a sparse group)
-        const bool maps = group < 2 ? p->maps_g0 : p->maps_g1;
+        const bool maps = group == 0 ? p->maps_g0 : p->maps_g1;
         if (maps)
             // (the MAPS form of a dense group wants every workgroup of the launch: 154 k keypoints 4.68 ms at 832, 4.48 at 960)
             hipLaunchKernelGGL(descriptor_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
@@ -839,6 +837,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
         else p->ev_pyr.push_back(e);
     }
     if (!rc) rc = p->alloc(&p->tmp, N * sizeof(float));
+    if (!rc && p->n_oct > 2) rc = p->alloc(&p->tmp_below, (size_t)p->ow[2] * p->oh[2] * sizeof(float));
     if (!rc) rc = p->alloc(&p->raw, N * (dtype_size(in_dtype) > 4 ? dtype_size(in_dtype) : 4));
     if (!rc && in_dtype != SIFTMI_F32) rc = p->alloc(&p->conv, N * sizeof(float));
 
@@ -955,7 +954,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
     else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
     else if (n == "desc_bucket") { if (v < 0) return fail(SIFTMI_EINVAL, "desc_bucket must be >= 0"); o.desc_bucket = v; }
-    else if (n == "split0") o.split0 = v != 0;
+    else if (n == "fork") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fork must be 0 (never), 1 (always) or 2 (frames of five octaves and more)"); o.fork = v; }
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
     else if (n == "spin") o.spin = v != 0;
@@ -1077,21 +1076,20 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
 int enqueue_body(siftmi_plan *p) {
     char lab[96];
     // Streams (option "overlap"; a single-stream plan runs the same launches in this order on `stream`):
-    //   stream  : octave 0 end to end -- pyramid, detection, orientation, descriptors, read-back of the counters;
-    //   stream2 : octave 0 split by scale (option "split0", planes the marching blur takes): detection scale 1 needs planes
-    //             0-3 only, so its detection, refinement, orientation and descriptors (group 0) start when plane 3 exists,
-    //             under the octave's last two blurs, and `stream` carries scales 2-3 (group 1) behind the pyramid;
-    //             unsplit: octave 0's gradient maps beside its detection (keypoint-rich frames);
-    //   stream3 : the later octaves -- pyramids from octave 0's plane 3 on, detection, the tail launch, group 2's
-    //             orientation and descriptors.
-    // The groups have their own lists and counters and meet only in the record list (descriptor_reserve): nothing orders
-    // them but the two pyramid events.  Octave planes are never rewritten.
+    //   stream  : octave 0 end to end -- pyramid, detection, orientation, descriptors (group 0), read-back of the counters;
+    //   stream3 : octave 1 from octave 0's pyramid on -- its pyramid, detection, orientation and descriptors (group 1);
+    //   stream2 : the octaves below (option "fork"), from the moment octave 1's plane 3 exists -- pyramids, detection, the tail
+    //             launch, orientation and descriptors (group 2); before that, octave 0's gradient maps on keypoint-rich frames.
+    // The groups have their own lists and counters and meet only in the record list (descriptor_open): nothing orders them
+    // but the two pyramid events.  Octave planes are never rewritten.  (Round 4 had one chain for all later octaves, whose
+    // detection also waited for the end of octave 0's orientation pass -- the lists were shared; that chain ended the frame,
+    // ~75 us after octave 0's descriptors, on a nearly idle chip.  Round 5 also tried octave 0 in two groups -- scale 1 from
+    // plane 3 on, under the last two blurs: 0.86 against 0.80 ms, the blurs beside it slow down by more than the chain gains.)
     const bool two = p->overlap && p->n_oct > 0;
     const int tail_first = tail_first_octave(p);
     p->tail_first_cur = tail_first;
     p->groups_cur = 0;
     for (hipStream_t &w : p->wait_s) w = nullptr;
-    const int border = p->par.border_dist;
     // Gradient maps for the per-keypoint kernels of this image (option "maps"): large frames, by the previous image's counts
     {
         const int mode = p->opt.maps;
@@ -1125,12 +1123,11 @@ int enqueue_body(siftmi_plan *p) {
         p->maps_g0 = want0; p->maps_g1 = want1;
         if (want0 && two && !p->ev_maps0) HIPCHK(hipEventCreateWithFlags(&p->ev_maps0, SIFT_SYNC_EVENT));
     }
-    // Octave 0 in two groups: large planes, two streams, no stage-by-stage profile (every stage keeps one launch and label
-    // there), the lazy-gradient forms (a keypoint-rich frame builds its maps from the complete pyramid)
-    const bool split0 = two && p->opt.split0 && p->n_oct > 0 && p->profile <= 1 && !p->maps_g0 && p->grp[1].okp &&
-                        march_plane(p->ow[0], p->oh[0]) && p->ow[0] > 2 * border && p->oh[0] > 2 * border;
-    p->split_cur = split0;
-    hipStream_t later = two ? p->stream3 : p->stream;       // the later octaves' chain
+    // the later octaves in two chains: two streams, an octave 1 outside the tail launch, at least one octave below it
+    const bool fork = two && (p->opt.fork == 1 || (p->opt.fork == 2 && p->n_oct >= 5)) && p->n_oct > 2 && tail_first != 1 && p->grp[1].okp;
+    p->fork_cur = fork;
+    hipStream_t later = two ? p->stream3 : p->stream;       // octave 1's chain (every later octave's without the fork)
+    hipStream_t below = fork ? p->stream2 : later;          // the chain of the octaves below octave 1
     bool handed[SIFT_MAX_OCTAVES + 1] = {false};   // plane 0 of the octave was written by the blur launch of the octave above
     hipEvent_t pyr0_done = nullptr;            // light profile: the blur bracket's closing event stands in for ev_pyr[0]
     int slot = 0;                              // read-back blocks used so far (one per ending stream)
@@ -1160,13 +1157,10 @@ int enqueue_body(siftmi_plan *p) {
                 Scope sc(p, lab, true, (double)W * H, pyr, p->profile > 1 ? oct : -2);      // (light profile: octave 0 is inside the open bracket, the others are not timed)
                 if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
             }
-            if (s == 2 && oct == 0 && split0) {
-                // plane 3 exists: scale 1 of octave 0 starts on stream2 (the record is a marker packet between two blurs)
+            if (s == 2 && oct == 1 && fork) {
+                // plane 3 of octave 1 and plane 0 of octave 2 exist (or will be shrunk from it): the chain below starts here
                 HIPCHK(hipEventRecord(p->ev_p3, pyr));
-                HIPCHK(hipStreamWaitEvent(p->stream2, p->ev_p3, 0));
-                launch_detect_octave(p, 0, p->stream2, 1);
-                int rc = launch_describe_group(p, 0, p->stream2, slot++);
-                if (rc) return rc;
+                HIPCHK(hipStreamWaitEvent(below, p->ev_p3, 0));
             }
         }
         if (oct == 0 && p->profile == 1) {
@@ -1191,24 +1185,29 @@ int enqueue_body(siftmi_plan *p) {
                 HIPCHK(hipEventRecord(p->ev_maps0, p->stream2));
             } else launch_gradient_maps(p, 0, 1, p->stream);
         }
-        launch_detect_octave(p, 0, p->stream, split0 ? 2 : 0);
+        launch_detect_octave(p, 0, p->stream);
         // octave 0's gradient maps ran beside detection and refinement: only orientation and description read them
         if (p->maps_g0 && two) HIPCHK(hipStreamWaitEvent(p->stream, p->ev_maps0, 0));
-        if ((rc = launch_describe_group(p, split0 ? 1 : 0, p->stream, slot++))) return rc;
+        if ((rc = launch_describe_group(p, 0, p->stream, slot++))) return rc;
     }
     if (p->n_oct > 1) {
-        // ---- the later octaves: group 2
+        // ---- the later octaves: octave 1 (group 1 when the chain forks, else part of group 2), then the octaves below (group 2)
         if (two) HIPCHK(wait_pyr0(later));
         for (int oct = 1; oct < p->n_oct; oct++) {
+            hipStream_t st = (oct == 1) ? later : below;
             if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp)
-                if ((rc = launch_tail(p, oct, later))) return rc;
+                if ((rc = launch_tail(p, oct, st))) return rc;
                 break;
             }
-            if ((rc = build_pyramid(oct, later))) return rc;
-            launch_detect_octave(p, oct, later);
+            if ((rc = build_pyramid(oct, st))) return rc;
+            launch_detect_octave(p, oct, st);
+            if (oct == 1 && fork) {
+                if (p->maps_g1) launch_gradient_maps(p, 1, 2, later);
+                if ((rc = launch_describe_group(p, 1, later, slot++))) return rc;
+            }
         }
-        if (p->maps_g1) launch_gradient_maps(p, 1, p->n_oct, later);
-        if ((rc = launch_describe_group(p, 2, later, slot++))) return rc;
+        if (p->maps_g1) launch_gradient_maps(p, fork ? 2 : 1, p->n_oct, below);
+        if ((rc = launch_describe_group(p, 2, below, slot++))) return rc;
     }
     if (p->chain) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }   // no octave closed the light-profile bracket (n_oct == 0)
     if (slot == 0) {                           // no octave at all: the counters (min / max) still come back
@@ -1346,7 +1345,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     }
     p->last_count = n;
     p->last_overflow = ovf;
-    p->last_group0 = (int)std::min<int64_t>((int64_t)hc.g_out[0] + (p->split_cur ? hc.g_out[1] : 0), n);
+    p->last_group0 = (int)std::min<int64_t>(hc.g_out[0], n);
     p->last_group1 = (int)n - p->last_group0;
     *n_out = n;
     if (overflow) *overflow = ovf;

@@ -95,8 +95,7 @@ int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
  *   launch shapes      "march", "march_wgs", "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
  *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks",
- *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_bucket" (groups below that many
- *                      keypoints are described detection scale 3 first; 0: list order), "desc_stream", "maps_blocks"
+ *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_stream", "maps_blocks"
  *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",
  *                      "maps" (0 never / 1 always / 2 by the previous image's count), "maps_density"
  *   stream schedule    "overlap" (0: one stream), "fork" (the octaves below octave 0 as two chains and groups -- octave 1 | the rest: 0 never, 1 always, 2 from five octaves), "spin"

@@ -702,11 +702,6 @@ __device__ __forceinline__ void desc_one_wave(const OctaveTable &tab, const floa
 // `next`: device counter for dynamic hand-out (null: static stride).  Every wave takes keypoint `start + its index` first;
 // after that it asks the counter, so that a wave with a small window does not idle while another still has two large
 // ones to go (windows differ by 4x in samples within an octave).
-// `ord` (null: list order): the group's three hand-out lists (k_keypoint.hpp: orientation_kernel), `ord_stride` entries apart,
-// holding n1 / n2 / n3 keypoints of detection scales 1 / 2 / 3.  Hand-out position u walks scale 3, then 2, then 1: a window
-// has 17 to 75 batches of samples and grows with the scale, so the launch ends on its smallest windows (in list order it
-// ended with whatever large windows were handed out last on an otherwise idle chip: the longest wave ran 2.4x the mean,
-// profiles/r04/phase_clock_white4096.txt).  Nothing is sorted: the orientation launch appends to the list of the scale.
 template <bool MAPS>
 __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const float4 *__restrict__ okp, const int *__restrict__ oaux,
                                                  int start, int end, const RecordSink *sink, DescRowLds *lds_all, double *fold, int *next, int nblocks) {
@@ -733,8 +728,7 @@ __device__ __forceinline__ void descriptor_waves(const OctaveTable &tab, const f
         return start + nwaves + t;
     };
     for (int t = start + gwave; t < end; t = advance(t)) {
-        // hand-out position t -> keypoint i: list order, or scale 3 first
-        const int i = start + handout_index(sink, t - start);
+        const int i = t;                 // list order (see the note on hand-out orders above descriptor_kernel)
         // the keypoint is the same in every lane: keep its integer attributes in scalar registers
         float4 kq = okp[i];              // (x, y, sigma*oct, angle)
         kq.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kq.x)));
@@ -926,6 +920,14 @@ __device__ __forceinline__ void descriptor_team(const OctaveTable &tab, const fl
     }
 }
 
+// Hand-out order of the wave form: list order.  Largest windows first shortens the launch (a window has 17 to 75 batches of
+// samples; in list order the longest wave runs 2.4x the mean) but never the frame: round 3's counting sort over 16 size classes
+// (launch of the headline frame 336 -> 285 us alone) sat on the critical path; round 5 had the orientation launch append every
+// keypoint to one of three per-scale lists for free and walked them scale 3 first -- launch alone 278 -> 250 us, whole call
+// 0.789 / 0.795 ms with / without on the headline frame, +1.3 % on 4096^2 with every octave, +1.4 ... 3.5 % on keypoint-rich
+// frames (neighbours in the list are neighbours in the image and share their window pixels in the caches).  The later
+// octaves' chain ends the frame, and what slows that chain is the resources this launch holds, not how long it holds them.
+//
 // The launch: both forms share the grid (workgroups of four waves), the LDS block and the fold table; the count of the
 // group decides -- fewer than `team_below` oriented keypoints: a workgroup per keypoint, else a wave per keypoint.
 // Measured cross-over 1000-1800 keypoints (a 256-CU device holds 1024 workgroups of this kernel at once).
@@ -940,16 +942,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIFT_DESC_W
 void descriptor_kernel(OctaveTable tab, const float4 *__restrict__ okp, const int *__restrict__ oaux, Counters *cnt,
                        int group, int range_start, int range_end,   // range used when cnt == nullptr
                        int out_capacity, KpRecord *__restrict__ records, int rec_capacity, KpRecord *host_records, int host_capacity,
-                       int team_below, int dynamic, int dense_blocks, int small_blocks, const int *__restrict__ ord, int bucket_below) {
+                       int team_below, int dynamic, int dense_blocks, int small_blocks) {
     __shared__ DescLds lds;
     __shared__ double fold[36];
     __shared__ RecordSink sink;
     int start = range_start, end = range_end;
     if (cnt) { start = 0; end = min(cnt->g_out[group], out_capacity); }
-    // scale 3 first (the hand-out lists) for groups below `bucket_below` keypoints whose lists are complete; list order otherwise
-    const bool bucketed = cnt && ord && end - start >= team_below && end - start < bucket_below && cnt->g_out[group] <= out_capacity &&
-                          cnt->g_ord[group][0] + cnt->g_ord[group][1] + cnt->g_ord[group][2] == end;
-    descriptor_open(cnt, group, end, records, rec_capacity, host_records, host_capacity, bucketed ? ord : nullptr, out_capacity, &sink);   // (before any workgroup leaves)
+    descriptor_open(cnt, group, end, records, rec_capacity, host_records, host_capacity, &sink);   // (before any workgroup leaves)
     if (end - start < team_below) descriptor_team<MAPS>(tab, okp, oaux, start, end, &sink, lds.team, fold);
     else {
         // three workgroups per CU instead of four on a dense group: 154 k keypoints 5.56 -> 5.45 ms per call (the 9 k

@@ -75,7 +75,6 @@ struct Counters {
     unsigned rec_word[SIFT_GROUPS];     // 0x80000000 | first record of the group's block, once the block is reserved (0 before)
     int g_kp[SIFT_GROUPS];              // refined keypoints appended to the group's list (may exceed its capacity: the host grows the list)
     int g_out[SIFT_GROUPS];             // oriented keypoints appended to the group's list (likewise)
-    int g_ord[SIFT_GROUPS][3];          // ... by detection scale: entries of the group's three hand-out lists
     int desc_next[SIFT_GROUPS];         // descriptor_kernel: keypoints of the group handed out beyond every wave's first one
     int n_cand[SIFT_MAX_OCTAVES + 1];   // candidates per octave ([SIFT_MAX_OCTAVES]: scales 2-3 of a split octave 0)
     // What the reference's per-octave keypoint counter would have held (plan.py:626-731, one counter per octave, reset by
@@ -101,7 +100,7 @@ __device__ __forceinline__ size_t map_offset(const OctaveTable &tab, int oct, in
     return (size_t)(tab.off[oct] / 2) + (size_t)(scale - 1) * tab.W[oct] * tab.H[oct];
 }
 
-// Where the records of a group go, and how its keypoints are handed out: filled once per workgroup of a descriptor launch
+// Where the records of a group go: filled once per workgroup of a descriptor launch
 // (descriptor_open) and kept in LDS -- a record's addresses are formed from here, in vector registers, at the moment the
 // record leaves (nothing of it lives in the scalar registers a descriptor needs for its window).
 // Keypoint i of the group's oriented list is record i of the group's block; a record beyond a list's capacity is not
@@ -110,8 +109,6 @@ __device__ __forceinline__ size_t map_offset(const OctaveTable &tab, int oct, in
 struct alignas(16) RecordSink {
     KpRecord *dev, *host;          // the group's block in the device list / in the caller's pinned array (or null)
     int dev_limit, host_limit;     // keypoints of the group that fit each
-    const int *ord;                // the group's three hand-out lists (null: list order), ord_stride entries apart,
-    int ord_stride, n3, n23;       // ... entries of scale 3, of scales 3 and 2
 };
 
 // The record block of a group: workgroup 0 of the group's descriptor launch reserves [base, base + n) of the image's
@@ -121,7 +118,7 @@ struct alignas(16) RecordSink {
 // result array -- without an event between them and without an atomic per keypoint.
 // Call with every thread of the workgroup (it ends with a workgroup barrier); cnt == null: no block, base 0.
 __device__ __forceinline__ void descriptor_open(Counters *cnt, int group, int n, KpRecord *records, int rec_capacity, KpRecord *host_records,
-                                                int host_capacity, const int *ord, int ord_stride, RecordSink *S) {
+                                                int host_capacity, RecordSink *S) {
     if (threadIdx.x == 0) {
         int base = 0;
         if (cnt) {
@@ -138,21 +135,8 @@ __device__ __forceinline__ void descriptor_open(Counters *cnt, int group, int n,
         }
         S->dev = records + base; S->dev_limit = rec_capacity - base;
         S->host = host_records ? host_records + base : nullptr; S->host_limit = host_records ? host_capacity - base : 0;
-        S->ord = ord; S->ord_stride = ord_stride;
-        S->n3 = (cnt && ord) ? cnt->g_ord[group][2] : 0;
-        S->n23 = (cnt && ord) ? cnt->g_ord[group][2] + cnt->g_ord[group][1] : 0;
     }
     __syncthreads();
-}
-
-// hand-out position u of the group -> keypoint (wave uniform): list order, or detection scale 3, then 2, then 1
-__device__ __forceinline__ int handout_index(const RecordSink *S, int u) {
-    const volatile RecordSink *v = S;
-    const int *ord = v->ord;
-    if (!ord) return u;
-    const int n3 = v->n3, n23 = v->n23, stride = v->ord_stride;
-    const int *src = u < n3 ? ord + 2 * (size_t)stride + u : (u < n23 ? ord + (size_t)stride + (u - n3) : ord + (u - n23));
-    return __builtin_amdgcn_readfirstlane(*src);
 }
 
 // The 144-byte record of keypoint i of the group leaves the wave as 36 coalesced dwords (lanes 0-3: x, y, scale, angle;
@@ -269,7 +253,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
                                                           const float4 *__restrict__ kp,
                                                           const int *__restrict__ kp_aux, Counters *cnt, int group,
                                                           int kp_capacity, float4 *__restrict__ okp,
-                                                          int *__restrict__ oaux, int *__restrict__ ord, int out_capacity, int team_below, int small_blocks) {
+                                                          int *__restrict__ oaux, int out_capacity, int team_below, int small_blocks) {
     __shared__ OriWaveLds lds_all[4];
     __shared__ double fold[36];
     __shared__ int s_hist[3 * SIFT_MAX_OCTAVES];          // oriented keypoints per (octave, detection scale): Counters::o_scale
@@ -297,41 +281,19 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (nblocks * blockDim.x) >> 6;
     const float4 *pool4 = reinterpret_cast<const float4 *>(L.pool);
-    __shared__ int s_pending[4], s_scale[4][3], s_base[4];
+    __shared__ int s_pending[4], s_base;
     int pending = 0;                     // entries parked in L.obuf (wave uniform)
-    int ps0 = 0, ps1 = 0, ps2 = 0;       // ... of detection scales 1 / 2 / 3 (a keypoint's entries share its scale)
-    // Parked entries [0, count) -> list positions slot + e, and their positions into the group's three hand-out lists
-    // (ord + (scale - 1) * out_capacity, from b0 / b1 / b2 on): the descriptor launch hands the group out scale 3 first --
-    // a window grows with the detection scale, and a launch that ends on small windows has a short tail (k_descriptor.hpp).
-    auto store_pending = [&](int slot, int b0, int b1, int b2, int count) {
+    auto store_pending = [&](int slot, int count) {
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long below = (1ull << lane) - 1ull;
-        for (int e0 = 0; e0 < count; e0 += 64) {          // wave uniform
-            const int e = e0 + lane;
-            const bool act = e < count;
-            const int aux = act ? L.oaux[e] : 0;
-            const int sc = aux & 0xff;
-            const unsigned long long m0 = __ballot(act && sc <= 1), m1 = __ballot(act && sc == 2), m2 = __ballot(act && sc >= 3);
-            if (act && slot + e < out_capacity) {
-                okp[slot + e] = L.obuf[e];
-                oaux[slot + e] = aux;
-                if (ord) {
-                    const int pos = sc <= 1 ? b0 + __popcll(m0 & below) : (sc == 2 ? b1 + __popcll(m1 & below) : b2 + __popcll(m2 & below));
-                    if (pos < out_capacity) ord[(size_t)min(max(sc - 1, 0), 2) * out_capacity + pos] = slot + e;
-                }
-            }
-            b0 += __popcll(m0); b1 += __popcll(m1); b2 += __popcll(m2);
-        }
+        for (int e = lane; e < count; e += 64)
+            if (slot + e < out_capacity) { okp[slot + e] = L.obuf[e]; oaux[slot + e] = L.oaux[e]; }       // (a cut list shows in the counter: the host grows it)
         __builtin_amdgcn_wave_barrier();
     };
     auto flush_wave = [&]() {
-        int r = 0;
-        if (lane == 0) r = atomicAdd(&cnt->g_out[group], pending);
-        else if (lane == 1 && ps0) r = atomicAdd(&cnt->g_ord[group][0], ps0);
-        else if (lane == 2 && ps1) r = atomicAdd(&cnt->g_ord[group][1], ps1);
-        else if (lane == 3 && ps2) r = atomicAdd(&cnt->g_ord[group][2], ps2);
-        store_pending(__shfl(r, 0), __shfl(r, 1), __shfl(r, 2), __shfl(r, 3), pending);
-        pending = 0; ps0 = ps1 = ps2 = 0;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&cnt->g_out[group], pending);
+        store_pending(__shfl(slot, 0), pending);
+        pending = 0;
     };
     // Sparse groups (fewer than team_below keypoints): the four waves of a workgroup take ONE keypoint, each evaluates
     // every fourth batch of 64 window samples into its own vote masks / pool, and after a workgroup barrier the bin
@@ -529,24 +491,21 @@ __global__ __launch_bounds__(256) void orientation_kernel(OctaveTable tab, float
             L.oaux[at] = aux;
         }
         pending += nmain + nextra;
-        { const int add = nmain + nextra; ps0 += scale <= 1 ? add : 0; ps1 += scale == 2 ? add : 0; ps2 += scale >= 3 ? add : 0; }
         PH_MARK(7);
     }
-    // ---- the workgroup's remaining entries leave with one atomicAdd per counter (list slots, three hand-out lists)
-    if (lane == 0) { const int w = threadIdx.x >> 6; s_pending[w] = pending; s_scale[w][0] = ps0; s_scale[w][1] = ps1; s_scale[w][2] = ps2; }
+    // ---- the workgroup's remaining entries leave with a single atomicAdd
+    if (lane == 0) s_pending[threadIdx.x >> 6] = pending;
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const int t = threadIdx.x;
-        int tot = 0;
-        for (int q = 0; q < 4; q++) tot += t == 0 ? s_pending[q] : s_scale[q][t - 1];
-        s_base[t] = tot ? atomicAdd(t == 0 ? &cnt->g_out[group] : &cnt->g_ord[group][t - 1], tot) : 0;
+    if (threadIdx.x == 0) {
+        const int tot = s_pending[0] + s_pending[1] + s_pending[2] + s_pending[3];
+        s_base = tot ? atomicAdd(&cnt->g_out[group], tot) : 0;
     }
     __syncthreads();
     {
         const int w = threadIdx.x >> 6;
-        int slot = s_base[0], b0 = s_base[1], b1 = s_base[2], b2 = s_base[3];
-        for (int q = 0; q < w; q++) { slot += s_pending[q]; b0 += s_scale[q][0]; b1 += s_scale[q][1]; b2 += s_scale[q][2]; }
-        store_pending(slot, b0, b1, b2, pending);
+        int slot = s_base;
+        for (int q = 0; q < w; q++) slot += s_pending[q];
+        store_pending(slot, pending);
     }
     for (int t = threadIdx.x; t < 3 * SIFT_MAX_OCTAVES; t += blockDim.x)
         if (s_hist[t]) atomicAdd(&cnt->o_scale[0][0] + t, s_hist[t]);
@@ -597,7 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     DescWaveLds &L = lds_all[wave];
     int start = range_start, end = range_end;
     if (cnt) { start = 0; end = min(cnt->g_out[group], out_capacity); }
-    descriptor_open(cnt, group, end, records, rec_capacity, host_records, host_capacity, nullptr, 0, &sink);
+    descriptor_open(cnt, group, end, records, rec_capacity, host_records, host_capacity, &sink);
     L.mlo[lane] = 0u; L.mhi[lane] = 0u; L.mlo[lane + 64] = 0u; L.mhi[lane + 64] = 0u;
     if (lane == 0) L.pool_cnt = 0;
     const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;

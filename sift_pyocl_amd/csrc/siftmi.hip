@@ -123,8 +123,6 @@ struct Options {
     int desc_team = 2048;    // groups with fewer oriented keypoints than this are described by the workgroup-per-keypoint form (0: never); measured cross-over
                              // 1000-1800 alone (one workgroup slot per keypoint: 4 per CU); in a frame, round 4 (interleaved A/B, 1024 / 2048 / 3072 / 4096):
                              // 1024^2 smoothed 0.588 / 0.568 / 0.568 / 0.570 ms, 2048^2 white 0.500 / 0.499 / 0.520 / 0.521, headline and the other frames equal
-    int desc_bucket = 1 << 30;   // groups of fewer oriented keypoints than this are handed out scale 3 first in the wave form of the
-                             // descriptor launch (the three hand-out lists the orientation launch fills; 0: list order) -- see k_descriptor.hpp
     int fork = 2;            // the later octaves in two chains: octave 1 (detection to description, group 1) on `stream3`, the octaves below it
                              // (pyramids from octave 1's plane 3 on, the tail launch, group 2) on `stream2`.  0: one chain, one group; 1: always;
                              // 2: frames of at least five octaves.  Interleaved A/B, forked against one chain (white noise unless noted): 512^2
@@ -163,12 +161,10 @@ size_t dtype_size(int dt) {
 
 }  // namespace
 
-// The lists of one group of octaves (k_keypoint.hpp: Counters): refined keypoints, oriented keypoints, the three
-// hand-out lists of the descriptor launch.  Capacities start at kpsize (plan.py:243) and grow on demand (grow_lists).
+// The lists of one group of octaves (k_keypoint.hpp: Counters): candidates, refined keypoints, oriented keypoints.  Capacities start at kpsize (plan.py:243) and grow on demand (grow_lists).
 struct GroupLists {
     float4 *kp = nullptr;  int *kp_aux = nullptr;  int64_t cap_kp = 0;     // (peak, row, col, sigma), detection scale | octave << 8
     float4 *okp = nullptr; int *oaux = nullptr;    int64_t cap_out = 0;    // (x, y, scale, angle), same tag
-    int *ord = nullptr;                                                     // 3 x cap_out
     float4 *cand = nullptr; int64_t cap_cand = 0;                           // candidate list of the group's detection passes (one octave at a time)
 };
 
@@ -526,8 +522,7 @@ int grow_lists(siftmi_plan *p, const Counters *c, bool *grown = nullptr) {
             G.cap_kp = ck; if (grown) *grown = true;
         }
         if (co != G.cap_out) {
-            if ((rc = p->regrow(&G.okp, (size_t)G.cap_out * 16, (size_t)co * 16)) || (rc = p->regrow(&G.oaux, (size_t)G.cap_out * 4, (size_t)co * 4)) ||
-                (rc = p->regrow(&G.ord, (size_t)G.cap_out * 12, (size_t)co * 12))) return rc;
+            if ((rc = p->regrow(&G.okp, (size_t)G.cap_out * 16, (size_t)co * 16)) || (rc = p->regrow(&G.oaux, (size_t)G.cap_out * 4, (size_t)co * 4))) return rc;
             G.cap_out = co; if (grown) *grown = true;
         }
     }
@@ -676,11 +671,11 @@ void launch_orient_group(siftmi_plan *p, int group, hipStream_t st) {
     const bool maps = group == 0 ? p->maps_g0 : p->maps_g1;
     if (maps)
         hipLaunchKernelGGL(orientation_kernel<true>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                           (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, G.ord, (int)G.cap_out,
+                           (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, (int)G.cap_out,
                            p->opt.ori_team, p->opt.ori_small_blocks);
     else
         hipLaunchKernelGGL(orientation_kernel<false>, dim3((unsigned)ori_blocks), dim3(256), (size_t)ori_pad, st, tab, p->par.ori_sigma,
-                           (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, G.ord, (int)G.cap_out,
+                           (const float4 *)G.kp, (const int *)G.kp_aux, p->cnt, group, (int)G.cap_kp, G.okp, G.oaux, (int)G.cap_out,
                            p->opt.ori_team, p->opt.ori_small_blocks);
 }
 
@@ -709,11 +704,11 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
             // (the MAPS form of a dense group wants every workgroup of the launch: 154 k keypoints 4.68 ms at 832, 4.48 at 960)
             hipLaunchKernelGGL(descriptor_kernel<true>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                                (const float4 *)G.okp, (const int *)G.oaux, p->cnt, group, 0, 0, ocap, p->records, rcap, p->host_out, p->host_cap,
-                               p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks, (const int *)G.ord, p->opt.desc_bucket);
+                               p->opt.desc_team, p->opt.desc_dynamic, desc_blocks, small_blocks);
         else
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                                (const float4 *)G.okp, (const int *)G.oaux, p->cnt, group, 0, 0, ocap, p->records, rcap, p->host_out, p->host_cap,
-                               p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks, (const int *)G.ord, p->opt.desc_bucket);
+                               p->opt.desc_team, p->opt.desc_dynamic, p->opt.desc_dense_blocks, small_blocks);
     } else
         hipLaunchKernelGGL(descriptor_stream_kernel, dim3((unsigned)desc_blocks), dim3(256), (size_t)desc_pad, st, tab,
                            (const float4 *)G.okp, (const int *)G.oaux, p->cnt, group, 0, 0, ocap, p->records, rcap, p->host_out, p->host_cap);
@@ -877,7 +872,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
     for (GroupLists &G : p->grp)
-        for (void *q : {(void *)G.kp, (void *)G.kp_aux, (void *)G.okp, (void *)G.oaux, (void *)G.ord, (void *)G.cand}) if (q) hipFree(q);
+        for (void *q : {(void *)G.kp, (void *)G.kp_aux, (void *)G.okp, (void *)G.oaux, (void *)G.cand}) if (q) hipFree(q);
     if (p->records) hipFree(p->records);
     if (p->hb) hipHostFree(p->hb);
     if (p->ev_join) hipEventDestroy(p->ev_join);
@@ -953,7 +948,6 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "maps") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "maps must be 0 (never), 1 (always) or 2 (by the previous image)"); o.maps = v; }
     else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
     else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
-    else if (n == "desc_bucket") { if (v < 0) return fail(SIFTMI_EINVAL, "desc_bucket must be >= 0"); o.desc_bucket = v; }
     else if (n == "fork") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fork must be 0 (never), 1 (always) or 2 (frames of five octaves and more)"); o.fork = v; }
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
@@ -2326,7 +2320,7 @@ int siftmi_stage_orientation(int32_t dev, const float *blurs, int32_t W, int32_t
     HIPCHK(hipMemcpy(ks.p, aux.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(orientation_kernel<false>, dim3(grid_for(n * 64, 256, 1024)), dim3(256), 0, 0, tab,
                        par->ori_sigma, (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), cnt.as<Counters>(), 0, (int)n,
-                       o.as<float4>(), oa.as<int>(), (int *)nullptr, (int)capacity, 0, 512);
+                       o.as<float4>(), oa.as<int>(), (int)capacity, 0, 512);
     if ((rc = stage_end())) return rc;
     HIPCHK(hipMemcpy(&hc, cnt.p, sizeof hc, hipMemcpyDeviceToHost));
     int64_t m = hc.g_out[0] < capacity ? hc.g_out[0] : capacity;
@@ -2365,7 +2359,7 @@ int siftmi_stage_descriptor(int32_t dev, const float *blurs, int32_t W, int32_t 
         if (block_ok)
             hipLaunchKernelGGL(descriptor_kernel<false>, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (Counters *)nullptr, 0, 0, (int)n,
-                               (int)n, r.as<KpRecord>(), (int)n, (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30, (const int *)nullptr, 0);
+                               (int)n, r.as<KpRecord>(), (int)n, (KpRecord *)nullptr, 0, 0, 0, 1 << 30, 1 << 30);
         else
             hipLaunchKernelGGL(descriptor_stream_kernel, dim3(grid_for(n, 4, 2048)), dim3(256), 0, 0, tab,
                                (const float4 *)k.as<float4>(), (const int *)ks.as<int>(), (Counters *)nullptr, 0, 0, (int)n,

@@ -91,12 +91,6 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
     assert_same_keypoints(plan.keypoints(img), want, "gradient maps, one stream")
     plan.set_option("overlap", 1)
     plan.set_option("maps", 2)
-    # the descriptor launch in list order / scale 3 first ("desc_bucket": groups below that many keypoints)
-    for bucket in (0, 1 << 30):
-        plan.set_option("desc_bucket", bucket)
-        plan.set_option("desc_team", 0)                          # the wave-per-keypoint form is the one that follows the order
-        assert_same_keypoints(plan.keypoints(img), want, "desc_bucket %d" % bucket)
-    plan.set_option("desc_team", 1024)
     plan.pinned_results = False                                  # plain numpy result + device-to-host copy
     assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
     for init_sigma in (3.0, 4.0):
@@ -174,7 +168,7 @@ def test_small_frame_kernels_agree(siftlib, oracle, shape):
     if want is not None:
         assert_same_keypoints(base, want, "defaults vs oracle %r" % (shape,))
     for opts in (dict(tail=0), dict(tail=0, ext_rows=32), dict(tail=1, ext_rows=8), dict(tail=1, overlap=0),
-                 dict(desc_bucket=0), dict(desc_team=0), dict(desc_team=1 << 30, fork=0), dict(fork=1),
+                 dict(desc_team=0), dict(desc_team=1 << 30, fork=0), dict(fork=1),
                  dict(desc_team=0, desc_dynamic=0, desc_blocks=333), dict(desc_team=0, desc_blocks=7, ori_blocks=77), dict(ori_team=0), dict(ori_team=1 << 30, ori_blocks=5), dict(fused_shrink=0), dict(fused_shrink=1, overlap=0, tail=0), dict(fused_refine=0), dict(fused_refine=2, tail=0)):
         other = sp.SiftPlan(template=img)
         for name, value in opts.items():

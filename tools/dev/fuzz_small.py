@@ -22,7 +22,7 @@ for it in range(n):
     plan = sp.SiftPlan(template=img)
     if it % 4 == 1: plan.set_option("desc_team", 0); plan.set_option("ori_team", 0)
     if it % 4 == 2: plan.set_option("overlap", 0)
-    if it % 4 == 3: plan.set_option("fork", 0); plan.set_option("desc_bucket", 0)
+    if it % 4 == 3: plan.set_option("fork", 0)
     got = plan.keypoints(img)
     assert_same_keypoints(got, want, "fuzz %d %dx%d %s" % (it, H, W, np.dtype(dt).name))
     assert_same_keypoints(plan.keypoints(img), want, "fuzz %d second call" % it)

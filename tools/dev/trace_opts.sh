@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: kernel timeline of one keypoints() call with plan options:  bash tools/dev/trace_opts.sh "split0=0,desc_bucket=0" [size] [octaves] [kind]
+# dev: kernel timeline of one keypoints() call with plan options:  bash tools/dev/trace_opts.sh "fork=1" [size] [octaves] [kind]
 OPTS=${1:-base=1}; SIZE=${2:-4096}; OCT=${3:-3}; KIND=${4:-white}
 R=$(pwd); OUT=$R/gpurun_out/trace_opts; rm -rf $OUT; mkdir -p $OUT
 cat > $OUT/run.py <<PY

@@ -10,8 +10,8 @@ unless it already runs under a launcher (WORLD_SIZE set, e.g. `python -m torch.d
 config c2 (default, BASELINE.json configs[1]): a step = one SiftPlan.keypoints() over one 4096x4096 fp32 synthetic image
 (uniform white noise) that is already resident in HBM when the timed region starts; 3 octaves x 3 scales.  With N > 1
 each rank processes its own images -- independent units, no data-path collective ("weak" scaling) -- and the timed
-region ends with the one exchange step of the batched path: an all-gather of the keypoint records of the last step,
-from device memory (no host staging).
+region ends with the one exchange step of the batched path: an all-gather of the keypoint records of ALL K timed steps
+(each step's records are kept in an arena in HBM by one device-to-device copy), from device memory (no host staging).
 
 config c4 (BASELINE.json configs[3]): a step = one batch of 64 frames of 2048x2048 fp32, frame i owned by rank i mod N,
 each rank's share pipelined through a BatchPlan, then the all-gather of EVERY frame's records on device tensors.  The
@@ -37,6 +37,13 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PROFILE_DIR = "profiles/r05"           # the round's rocprofv3 summaries (tools/collect_round.sh); replayed only for the library they describe
+
+
+def library_fingerprint():
+    from sift_pyocl_amd import _lib
+    return _lib.source_fingerprint()
+
 
 import numpy as np  # noqa: E402
 
@@ -150,11 +157,15 @@ def roofline_valu(ms_per_step):
     """Issue time of one headline frame's VALU instructions (committed PMC counts x measured issue intervals) against the
     measured time of a step.  `frac` = the share of a step during which every SIMD of the chip would have to issue VALU
     instructions back to back; the counts are replayed from the committed file, not observed in this run."""
-    rel = "profiles/r04/valu_frame.json"
+    rel = PROFILE_DIR + "/valu_frame.json"
     try:
         vf = json.load(open(os.path.join(ROOT, rel)))
     except Exception:
         return None
+    if vf.get("library_fingerprint") != library_fingerprint():
+        # counts of other kernels than the ones loaded: not replayed (the summary has to be collected again: tools/valu_frame.sh)
+        return {"bound": "valu", "achieved": None, "frac": None, "source": "%s was taken from a library with other sources (fingerprint %s, "
+                "loaded %s): not replayed" % (rel, vf.get("library_fingerprint"), library_fingerprint())}
     cycles = 0.0
     instr = 0.0
     for fam, d in vf["families"].items():
@@ -179,7 +190,8 @@ def roofline_valu(ms_per_step):
             "issue_ms_if_all_half_rate": round(instr * 4.2 / (VALU_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3, 4),
             "simds": VALU_SIMDS, "clock_ghz": VALU_CLOCK_GHZ, "cycles_per_class": VALU_CYCLES,
             "source": "instruction counts replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU* of this command, tools/valu_frame.sh); "
-                      "issue intervals from profiles/r04/valu_issue_rate.txt (tools/ubench/valu_rate.hip)" % rel}
+                      "issue intervals from profiles/r04/valu_issue_rate.txt (tools/ubench/valu_rate.hip); fingerprint of the library's "
+                      "sources %s = the loaded one" % (rel, library_fingerprint())}
 
 
 def leg_c3(sp, torch, local_rank, size=16384, steps=3):
@@ -483,15 +495,36 @@ def main():
         dev_images = [torch.from_numpy(make_image(rank * 1000 + i, size)).cuda() for i in range(n_img)]
         torch.cuda.synchronize()
 
+        # N > 1 (SURVEY 8d "C2-scaling": total Mpix / wall time INCLUDING the final all-gather of every image's records):
+        # each step's records are kept where the descriptor kernels left them -- one device-to-device copy out of the plan's
+        # list into this rank's arena -- and ONE exchange at the end of the timed region gathers the records of all K frames
+        # of all ranks on device tensors (counts, then the padded record bytes): no host staging.
+        kept = {"counts": [], "used": 0, "arena": None}
+
+        def keep_records():
+            rec_view = plan.device_records()
+            n = rec_view.count
+            need = kept["used"] + n * 144
+            if kept["arena"] is None or need > kept["arena"].numel():
+                grown = torch.empty(max(need * 2, (K + 1) * max(n, 1024) * 216), dtype=torch.uint8, device=torch.device("cuda", local_rank))
+                if kept["used"]:
+                    grown[:kept["used"]] = kept["arena"][:kept["used"]]
+                kept["arena"] = grown
+            if n:
+                kept["arena"][kept["used"]:need] = torch.as_tensor(rec_view, device=torch.device("cuda", local_rank))
+            kept["counts"].append(n)
+            kept["used"] = need
+
         def exchange():
-            """the batched path's single exchange step, here for the records of the last frame: device tensors in,
-            device tensor out (the records are still in the plan's HBM list: no host staging)"""
-            counts = [plan.device_records().count]
-            rec = torch.as_tensor(plan.device_records(), device=torch.device("cuda", local_rank))
-            return gather_records_device(counts, xfer(rec), world, rank, world)
+            counts, used = kept["counts"], kept["used"]
+            out = gather_records_device(counts, xfer(kept["arena"][:used]), len(counts) * world, rank, world)
+            kept["counts"], kept["used"] = [], 0
+            return out, used
 
         for i in range(W):
             plan.keypoints(dev_images[i % n_img])
+            if distributed:
+                keep_records()
         if distributed:
             exchange()
         blur_ms = blur_px = tot_ms = b0_ms = b0_px = 0.0
@@ -500,11 +533,19 @@ def main():
         plan.profile_totals(reset=True)
         barrier()
         t0 = time.perf_counter()
+        exchange_ms = exchange_bytes = None
         for i in range(K):
             last = plan.keypoints(dev_images[i % n_img])
             n_kp += len(last)
+            if distributed:
+                keep_records()
         if distributed:
-            exchange()
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            (all_counts, gathered), exchange_bytes = exchange()
+            torch.cuda.synchronize()
+            exchange_ms = (time.perf_counter() - te) * 1e3
+            assert sum(sum(r) for r in all_counts) >= n_kp and gathered.shape[0] == world
         barrier()
         elapsed = time.perf_counter() - t0
         # hipEvent times of the K timed calls (the library sums them as the calls complete: one read-out, after the region)
@@ -527,7 +568,8 @@ def main():
         units = world * K * size * size / 1e6
         workload = ("SiftPlan %dx%d fp32 uniform white noise (numpy default_rng(seed).random), %d octaves x 3 scales, input "
                     "resident in HBM, records returned to host" % (size, size, n_oct))
-        result.update(scaling="weak", images_per_step=world, kp_per_img=n_kp / max(K, 1), n_oct=n_oct)
+        result.update(scaling="weak", images_per_step=world, kp_per_img=n_kp / max(K, 1), n_oct=n_oct,
+                      exchange_ms=None if exchange_ms is None else round(exchange_ms, 3), exchange_bytes=exchange_bytes)
         kt = dict(b0_ms=b0_ms, b0_px=b0_px, b0_launches=b0_launches, tot_ms=tot_ms, steady=steady)
 
     if distributed:
@@ -557,27 +599,32 @@ def main():
                        "keypoints_per_image": round(result["kp_per_img"], 1), "images_per_step": result["images_per_step"],
                        "exchange": ("all_gather of keypoint records on device tensors, backend %s, world size %d as seen by "
                                     "torch.distributed" % (backend, world_observed)) if distributed else "none",
+                       "exchange_ms": result.get("exchange_ms"), "exchange_bytes_per_rank": result.get("exchange_bytes"),
                        "backend": backend if distributed else None, "world_size_observed": world_observed},
         }
         if kt is not None:
             blur_gbs = (8.0 * kt["b0_px"] / 1e9) / (kt["b0_ms"] / 1e3) if kt["b0_ms"] > 0 else 0.0
             # HBM traffic per full-resolution blur launch: not observable from inside this process -- replayed from the
             # committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, tools/summarize_prof.py)
+            # -- and only while the summary was taken from a library of the same sources as the loaded one (its fingerprint)
             traffic, traffic_src = None, None
-            for rel in ("profiles/r04/blur_traffic.json", "profiles/r03/blur_traffic.json"):
-                tfile = os.path.join(ROOT, rel)
-                if os.path.exists(tfile) and size == SIZE and result["n_oct"] == OCTAVES:
-                    try:
-                        tj = json.load(open(tfile))
-                        # only a summary that covers all six full-resolution launches of every image of its run counts
-                        if tj.get("complete") and tj["launches_fetch_pass"] == 6 * tj["images_fetch_pass"] \
-                                and tj["launches_write_pass"] == 6 * tj["images_write_pass"]:
-                            traffic = round(tj["traffic_bytes_per_launch"], 1)
-                            traffic_src = ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %d + %d "
-                                           "launches = 6 per image; not observed in this run)" % (rel, tj["launches_fetch_pass"], tj["launches_write_pass"]))
-                            break
-                    except Exception:
-                        traffic = None
+            rel = PROFILE_DIR + "/blur_traffic.json"
+            tfile = os.path.join(ROOT, rel)
+            if os.path.exists(tfile) and size == SIZE and result["n_oct"] == OCTAVES:
+                try:
+                    tj = json.load(open(tfile))
+                    # only a summary that covers all six full-resolution launches of every image of its run counts
+                    if tj.get("library_fingerprint") != library_fingerprint():
+                        traffic_src = ("%s was taken from a library with other sources (fingerprint %s, loaded %s): not replayed"
+                                       % (rel, tj.get("library_fingerprint"), library_fingerprint()))
+                    elif tj.get("complete") and tj["launches_fetch_pass"] == 6 * tj["images_fetch_pass"] \
+                            and tj["launches_write_pass"] == 6 * tj["images_write_pass"]:
+                        traffic = round(tj["traffic_bytes_per_launch"], 1)
+                        traffic_src = ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %d + %d "
+                                       "launches = 6 per image, library fingerprint %s = the loaded one; not observed in this run)"
+                                       % (rel, tj["launches_fetch_pass"], tj["launches_write_pass"], library_fingerprint()))
+                except Exception:
+                    traffic = None
             # whole call: algorithmic bytes of an image over the wall time of a step (the light profile brackets only the blur
             # launches: every further event record between kernels would be a bubble in the timed region)
             pipe_ms = kt["tot_ms"] if kt["tot_ms"] > 0 else 1e3 * elapsed

@@ -104,6 +104,22 @@ _SIGNATURES = {
 }
 
 
+def source_fingerprint():
+    """sha256 (16 hex digits) over the sources libsiftmi.so is built from (csrc/*, include/siftmi.h).  Profile summaries that
+    bench.py replays beside a live measurement (HBM traffic, VALU instruction counts) carry the fingerprint of the
+    library they were taken from; a summary of other kernels is not replayed."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hpp")) + glob.glob(os.path.join(here, "csrc", "*.hip")) +
+                   [os.path.join(os.path.dirname(here), "include", "siftmi.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def exported_symbols():
     """Every entry point include/siftmi.h declares (checked against the .so by the CPU tests)."""
     return sorted(_SIGNATURES)

@@ -315,16 +315,19 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
         else:
             rank, world_size = 0, 1
     mine = shard_indices(len(images), rank, world_size)
+    plan_given = plan is not None
     if plan is None and mine:
         plan = BatchPlan(template=images[mine[0]], **plan_kwargs)
     # The exchange path must be the same on every rank, so it is chosen from rank-independent facts only: the backend
     # and the kind of plan the caller passed (a rank that owns no frame has no plan at all: plan is None there).
     nccl = gather and world_size > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
     on_device = nccl and (plan is None or isinstance(plan, BatchPlan))
-    if nccl:
-        # ... and agreed explicitly: a rank without frames (plan is None) would pick the device path while ranks that were
-        # handed a frame-by-frame SiftPlan pick the host-staged one -- two different collective sequences, i.e. a hang.
-        # One 4-byte all-reduce (MIN) of "this rank can take the device path" settles it for everybody.
+    if nccl and plan_given:
+        # ... and agreed explicitly where a caller's plan is involved: a rank without frames (plan is None) would pick the
+        # device path while ranks that were handed a frame-by-frame SiftPlan pick the host-staged one -- two different
+        # collective sequences, i.e. a hang.  One 4-byte all-reduce (MIN) of "this rank can take the device path" settles it
+        # for everybody.  (Without a caller's plan every rank builds a BatchPlan or has none: the device path on all of them,
+        # by construction -- no all-reduce, no blocking .item().  `plan_given` must be the same on every rank, as `images` is.)
         import torch
         flag = torch.tensor([1 if on_device else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -382,15 +385,24 @@ def match_sharded(kp1, kp2, plan=None, rank=None, world_size=None, device=None, 
     mine[:, 0] += lo
     if world_size == 1:
         return mine
-    nccl = dist.get_backend() == "nccl"
+    return gather_pairs(mine, world_size, device=device)
+
+
+def gather_pairs(mine, world_size, device=None, group=None):
+    """The exchange of ``match_sharded``: all-gather of the pair counts, then of the (i, j) pairs padded to the largest
+    count; with the "nccl" backend on device tensors.  Every rank returns the pairs of all ranks, in rank order."""
+    import torch
+    import torch.distributed as dist
+
+    nccl = dist.get_backend(group) == "nccl"
     dev = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu"))
     counts = torch.empty(world_size, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, torch.tensor([len(mine)], dtype=torch.int64, device=dev))
+    dist.all_gather_into_tensor(counts, torch.tensor([len(mine)], dtype=torch.int64, device=dev), group=group)
     counts = counts.cpu().tolist()
     width = max(1, max(counts))
     payload = torch.zeros((width, 2), dtype=torch.int32)
-    payload[:len(mine)] = torch.from_numpy(mine)
+    payload[:len(mine)] = torch.from_numpy(numpy.ascontiguousarray(mine, dtype=numpy.int32).reshape(-1, 2))
     gathered = torch.empty((world_size * width, 2), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(gathered, payload.to(dev))
+    dist.all_gather_into_tensor(gathered, payload.to(dev), group=group)
     gathered = gathered.cpu().numpy().reshape(world_size, width, 2)
     return numpy.concatenate([gathered[r, :counts[r]] for r in range(world_size)], axis=0)

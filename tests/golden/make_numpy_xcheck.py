@@ -62,6 +62,34 @@ def main():
         out["s%d_oriented" % s] = okp[:cnt].copy()
         ndesc = cnt
         out["s%d_desc" % s] = ns["my_descriptor"](okp[:ndesc].copy(), grad, ori, 1, 0, ndesc)
+    # ---- second image, two octaves: the facts only this repository's launch sequencer pinned until round 5 -- octsize = 2
+    # (the reference's own fixture uses it, test/test_image_setup.py:24-81): the EdgeThresh0 / EdgeThresh slot order of
+    # local_maxmin (is_maxmin picks by octsize, test_image_functions.py:85; plan.py:633-634 passes EdgeThresh1 first), the
+    # x = col * octsize scaling of orientation and descriptor -- on enough keypoints (> 500 descriptors).  The planes come from
+    # the oracle's blur (pinned bit for bit against the reference's convolution kernels, tests/test_oracle_golden.py): the numpy
+    # functions have no pyramid of their own beyond my_blur, and every stage below it is the reference's numpy code alone.
+    from oracle import pyoracle
+    from util import multiscale_noise, oracle_pyramid
+    img2 = multiscale_noise((300, 421))
+    for o, (blurs2, dogs2) in enumerate(oracle_pyramid(pyoracle, img2, 2)):
+        octsize = 1 << o
+        H2, W2 = dogs2.shape[1:]
+        for s in (1, 2, 3):
+            tag = "m_o%d_s%d_" % (o, s)
+            cand, n = ns["my_local_maxmin"](dogs2, peakthresh, 5, octsize, np.float32(0.08), np.float32(0.06), 20000, s, W2, H2)
+            cand = cand[:n]
+            out[tag + "candidates"] = cand
+            ref = np.array([ns["my_interp_keypoint"](dogs2, s, int(k[1]), int(k[2]), 5, peakthresh, W2, H2) for k in cand], np.float32).reshape(-1, 4)
+            out[tag + "interp"] = ref
+            grad, ori = ns["my_gradient"](blurs2[s])
+            kin = ref[ref[:, 1] != -1]                     # the numpy-refined keypoints feed the numpy orientation
+            nb = len(kin)
+            buf = -np.ones((4 * nb + 64, 4), np.float32)
+            buf[:nb] = kin
+            okp, cnt = ns["my_orientation"](buf, len(buf), 0, nb, grad, ori, octsize, np.float32(1.5))
+            out[tag + "oriented"] = okp[:cnt].copy()
+            out[tag + "desc"] = ns["my_descriptor"](okp[:cnt].copy(), grad, ori, octsize, 0, cnt)
+            print(tag, "candidates", n, "refined", nb, "oriented", cnt, flush=True)
     a, b = match_sets()
     na, nb_ = 300, 240
     da, db = a["desc"][:na].astype(np.int64), b["desc"][:nb_].astype(np.int64)

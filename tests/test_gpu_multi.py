@@ -35,6 +35,14 @@ def env():
     return e
 
 
+def free_port():
+    """a port nobody listens on right now (fixed ports collide with a lingering worker of an earlier run)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def bench(args, timeout=900):
     out = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          timeout=timeout, text=True, env=env())
@@ -44,7 +52,8 @@ def bench(args, timeout=900):
     return json.loads(lines[0])
 
 
-def run_worker(extra_env, port):
+def run_worker(extra_env, port=None):
+    port = port or free_port()
     e = env()
     e.update(extra_env)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -54,7 +63,7 @@ def run_worker(extra_env, port):
 
 @needs_two
 def test_sharded_paths_over_rccl_equal_one_rank():
-    out = run_worker({}, 29547)
+    out = run_worker({})
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert "multi ok: 2 ranks over nccl" in out.stdout
 
@@ -63,9 +72,20 @@ def test_worker_rehearsal_on_one_gpu():
     """The same worker script with both ranks on cuda:0 and gloo collectives: what can be checked of it on a one-GPU box
     (its frame / shard / match logic and the host-staged exchange), so that the RCCL run above does not meet the script
     for the first time on the day a second GPU appears."""
-    out = run_worker({"SIFT_MULTI_REHEARSAL": "1"}, 29548)
+    out = run_worker({"SIFT_MULTI_REHEARSAL": "1"})
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert "multi ok: 2 ranks over gloo" in out.stdout
+
+
+def test_rccl_call_path_on_one_gpu():
+    """RCCL itself on the GPU a one-GPU lease has: a world-size-1 "nccl" process group beside libsiftmi.so's HIP runtime, the
+    device-tensor collectives of the exchange on records the descriptor kernels wrote (tests/nccl_ws1_worker.py)."""
+    e = env()
+    e.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT=str(free_port()))
+    out = subprocess.run([sys.executable, os.path.join("tests", "nccl_ws1_worker.py")], cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600, text=True, env=e)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert "rccl ws1 ok" in out.stdout
 
 
 @needs_two
@@ -73,6 +93,7 @@ def test_bench_two_gpus_over_rccl():
     d = bench(["--gpus", "2", "--steps", "3", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["config"]["backend"] == "nccl"
     assert "all_gather" in d["config"]["exchange"] and d["scaling"] == "weak"
+    assert d["config"]["exchange_ms"] > 0 and d["config"]["exchange_bytes_per_rank"] > 3 * 144 * 5000      # the records of ALL timed steps
     assert abs(d["value"] - 2 * 4096 * 4096 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
 
 

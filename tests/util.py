@@ -105,6 +105,45 @@ def kp_digest(k):
     return out
 
 
+def oracle_pyramid(oracle, img, n_oct=1):
+    """[(blurs (6, H, W), dogs (5, H, W))] of the first `n_oct` octaves of `img`, computed by the oracle's stage functions in the
+    order of plan.py:525-539, 602-623, 740-745: normalise, initial blur, five blurs per octave, DoG, next octave = every second
+    sample of blur[3]."""
+    import math
+    mn, mx = oracle.minmax(img)
+    base = oracle.normalize(np.ascontiguousarray(img, np.float32), mn, mx)
+    base = oracle.blur(base, oracle.gaussian_taps(math.sqrt(1.6 ** 2 - 0.25), 15))
+    ratio = 2.0 ** (1.0 / 3.0)
+    out = []
+    for o in range(n_oct):
+        blurs, prev = [base], 1.6
+        for s in range(5):
+            inc = prev * math.sqrt(ratio ** 2 - 1.0)
+            size = int(math.ceil(8 * inc + 1)); size += (size % 2 == 0)
+            blurs.append(oracle.blur(blurs[-1], oracle.gaussian_taps(inc, size)))
+            prev *= ratio
+        blurs = np.ascontiguousarray(np.stack(blurs))
+        out.append((blurs, oracle.dog(blurs)))
+        base = oracle.shrink(blurs[3])
+    return out
+
+
+_MULT = None
+
+
+def kp_multiset_digest(k):
+    """Order-independent 128-bit digest of a keypoint set (the sum over its records of two 64-bit multilinear hashes of the
+    record's 18 quadwords): cheap enough to take thousands of times (the soak test), a changed, lost or doubled record changes it."""
+    global _MULT
+    if _MULT is None:
+        rng = np.random.default_rng(12345)
+        _MULT = (rng.integers(1, 2 ** 63, (2, 18), dtype=np.uint64) * np.uint64(2) + np.uint64(1))
+    q = np.ascontiguousarray(np.asarray(k)).view(np.uint64).reshape(-1, 18)
+    with np.errstate(over="ignore"):
+        h = [int((q * _MULT[i]).sum(axis=1, dtype=np.uint64).sum(dtype=np.uint64)) for i in range(2)]
+    return (len(q), h[0], h[1])
+
+
 # name -> (maker, shape, kwargs): the large cases pinned by digest (tests/golden/kp_digests.json)
 def digest_cases():
     return {"smooth2048": (smooth_noise, (2048, 2048), {}),

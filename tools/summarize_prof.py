@@ -15,6 +15,12 @@ import sys
 d = sys.argv[1]
 
 
+def _fingerprint():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sift_pyocl_amd import _lib
+    return _lib.source_fingerprint()
+
+
 def short(name):
     name = name.replace("siftk::", "").replace("void ", "")
     return name.split("(")[0]
@@ -102,6 +108,7 @@ if nb and nw:
     out = {"kernel_family": "blur, full-resolution (octave 0) launches", "launches_fetch_pass": nb, "launches_write_pass": nw,
            "images_fetch_pass": images_f, "images_write_pass": images_w, "launches_per_image": 6,
            "complete": bool(nb == 6 * images_f and nw == 6 * images_w),
+           "library_fingerprint": _fingerprint(),
            "fetch_size_bytes_per_launch_reported": fb / nb, "read_correction": 2.0,
            "write_size_bytes_per_launch": wb / nw,
            "traffic_bytes_per_launch": 2.0 * fb / nb + wb / nw,

@@ -52,6 +52,9 @@ lines.append("%-28s %10.3fM %7.2fM | %s | %7.2fM %7.2fM" % ("ALL", gsum["valu"] 
              " ".join("%8.2fM" % (gsum[k] / 1e6) for k in classes), gsum["other"] / 1e6, gsum["lds"] / 1e6))
 res["total"] = {"valu": gsum["valu"], "salu": gsum["salu"], "lds": gsum["lds"], "classes": {k: gsum[k] for k in classes}, "other": gsum["other"]}
 os.makedirs(out, exist_ok=True)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sift_pyocl_amd import _lib as _siftlib
+res["library_fingerprint"] = _siftlib.source_fingerprint()
 json.dump(res, open(os.path.join(out, "valu_frame.json"), "w"), indent=1)
 open(os.path.join(out, "valu_frame.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

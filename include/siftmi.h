@@ -108,9 +108,16 @@ int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 #define SIFTMI_OUT_HOST 0
 #define SIFTMI_OUT_DEVICE 1
 #define SIFTMI_OUT_PINNED 2
-/* pinned, device-writable host blocks from a size-bucketed pool (sizes round up to a power of two >= 64 KiB) */
+/* Pinned, device-writable host blocks from a size-bucketed pool (a power of two from 64 KiB to 1 MiB, a multiple of 2 MiB
+ * above).  The reference returns ordinary numpy arrays (plan.py:553-565); page-locked result arrays are this build's way to
+ * have no copy after the last kernel, and they cannot be swapped out: the pool holds at most `limit` bytes (default 2 GiB,
+ * live + spare) and siftmi_host_alloc returns SIFTMI_ENOMEM beyond it -- the Python layer then hands out an ordinary array.
+ * siftmi_host_free never calls the driver (it runs from destructors; hipHostFree synchronises the device): surplus blocks
+ * are released by the next siftmi_host_alloc or by siftmi_host_pool_trim(keep_bytes). */
 int siftmi_host_alloc(int64_t bytes, void **out);
 int siftmi_host_free(void *ptr);
+int siftmi_host_pool_limit(int64_t limit_bytes /* < 0: query only */, int64_t *live_bytes, int64_t *spare_bytes);
+int siftmi_host_pool_trim(int64_t keep_bytes);
 int siftmi_plan_keypoints(siftmi_plan *plan, const void *image, int32_t image_dtype, int32_t image_is_device,
                           siftmi_keypoint *out, int32_t out_is_device, int64_t capacity, int64_t *n_out,
                           int32_t *overflow);

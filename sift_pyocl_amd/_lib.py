@@ -44,6 +44,8 @@ _SIGNATURES = {
     "siftmi_plan_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "siftmi_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "siftmi_plan_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "siftmi_host_pool_limit": (C.c_int, [C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "siftmi_host_pool_trim": (C.c_int, [C.c_int64]),
     "siftmi_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
     "siftmi_host_free": (C.c_int, [C.c_void_p]),
     "siftmi_plan_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
@@ -182,6 +184,14 @@ def pinned_empty(count, dtype):
     dtype = numpy.dtype(dtype)
     block = PinnedBlock(max(1, count) * dtype.itemsize)
     return numpy.asarray(block)[:count * dtype.itemsize].view(dtype)
+
+
+def pinned_pool(limit=None):
+    """(live bytes, spare bytes) of the pinned result pool; `limit` (bytes) caps what it may hold -- beyond it results come
+    back as ordinary numpy arrays (one copy after the last kernel)."""
+    live, spare = C.c_int64(), C.c_int64()
+    check(lib().siftmi_host_pool_limit(-1 if limit is None else int(limit), C.byref(live), C.byref(spare)))
+    return int(live.value), int(spare.value)
 
 
 def last_error():

@@ -152,9 +152,15 @@ class LinearAlign(object):
         # the result image lives in a pinned block of the library's pool (recycled when the caller drops it): the copy out
         # of HBM runs at the link's rate, and no 64 MB mmap / munmap pair per aligned frame (see SiftPlan.keypoints)
         oshape, odtype = (self.outshape + (3,), numpy.uint8) if self.RGB else (self.outshape, numpy.float32)
-        try:
-            out = _lib.pinned_empty(int(numpy.prod(oshape)), odtype).reshape(oshape)
-        except MemoryError:
+        # (sift.pinned_results = False opts out, as for keypoints(); beyond the pool's limit -- _lib.pinned_pool -- the call gets an
+        # ordinary array as well: a stack-alignment loop that keeps every aligned frame must not pin the whole stack)
+        out = None
+        if getattr(self.sift, "pinned_results", True):
+            try:
+                out = _lib.pinned_empty(int(numpy.prod(oshape)), odtype).reshape(oshape)
+            except MemoryError:
+                out = None
+        if out is None:
             out = numpy.empty(oshape, odtype)
         ptr = None
         if image is not None:

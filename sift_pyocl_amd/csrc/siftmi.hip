@@ -1411,53 +1411,108 @@ struct HostPool {
     std::mutex mu;
     std::unordered_map<void *, size_t> live;                 // block -> bucket size
     std::unordered_map<size_t, std::vector<void *>> spare;   // bucket size -> free blocks
+    std::vector<void *> trash;                               // blocks to hand back to the driver at the next allocation
+    size_t live_bytes = 0, spare_bytes = 0;                  // handed out / parked in `spare`
+    size_t limit = (size_t)2 << 30;                          // page-locked bytes the pool may hold in all (siftmi_host_pool_limit)
     static constexpr size_t kKeep = 8;                        // spare blocks kept per bucket
 };
 HostPool &host_pool() { static HostPool *hp = new HostPool(); return *hp; }   // leaked on purpose: no teardown order issues
+// Sizes round up to a power of two from 64 KiB to 1 MiB and to a multiple of 2 MiB above (a 3000 x 3000 float32 frame takes
+// 36 MiB, not 64: a stack-alignment loop keeps every aligned frame alive, and page-locked memory cannot be swapped).
+size_t host_bucket(size_t bytes) {
+    size_t bucket = (size_t)1 << 16;
+    while (bucket < bytes && bucket < ((size_t)1 << 20)) bucket <<= 1;
+    if (bucket < bytes) bucket = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+    return bucket;
+}
 }  // namespace
 extern "C" {
+
+// The pool never holds more than `limit` bytes of page-locked memory (live + spare): beyond it siftmi_host_alloc returns
+// SIFTMI_ENOMEM and the Python layer hands out an ordinary array instead (one copy after the last kernel).
+int siftmi_host_pool_limit(int64_t limit_bytes, int64_t *live_bytes, int64_t *spare_bytes) {
+    HostPool &hp = host_pool();
+    std::lock_guard<std::mutex> g(hp.mu);
+    if (limit_bytes >= 0) hp.limit = (size_t)limit_bytes;
+    if (live_bytes) *live_bytes = (int64_t)hp.live_bytes;
+    if (spare_bytes) *spare_bytes = (int64_t)hp.spare_bytes;
+    return SIFTMI_OK;
+}
 
 int siftmi_host_alloc(int64_t bytes, void **out) {
     if (!out || bytes < 0) return fail(SIFTMI_EINVAL, "bad argument");
     *out = nullptr;
-    size_t bucket = (size_t)1 << 16;
-    while (bucket < (size_t)bytes) bucket <<= 1;
+    const size_t bucket = host_bucket((size_t)bytes);
     HostPool &hp = host_pool();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> g(hp.mu);
+        drop.swap(hp.trash);
+    }
+    for (void *q : drop) (void)hipHostFree(q);           // (what siftmi_host_free set aside: released here, in a caller's context)
+    drop.clear();
     {
         std::lock_guard<std::mutex> g(hp.mu);
         auto it = hp.spare.find(bucket);
         if (it != hp.spare.end() && !it->second.empty()) {
             void *q = it->second.back();
             it->second.pop_back();
-            hp.live[q] = bucket;
+            hp.spare_bytes -= bucket;
+            hp.live[q] = bucket; hp.live_bytes += bucket;
             *out = q;
             return SIFTMI_OK;
         }
+        if (hp.live_bytes + bucket > hp.limit)
+            return fail(SIFTMI_ENOMEM, "pinned result pool: %zu bytes live, %zu more would pass the limit of %zu (siftmi_host_pool_limit)",
+                        hp.live_bytes, bucket, hp.limit);
+        // room for the new block: spare blocks of other sizes go first
+        for (auto &kv : hp.spare) {
+            while (hp.live_bytes + hp.spare_bytes + bucket > hp.limit && !kv.second.empty()) {
+                drop.push_back(kv.second.back()); kv.second.pop_back(); hp.spare_bytes -= kv.first;
+            }
+        }
     }
+    for (void *q : drop) (void)hipHostFree(q);
     void *q = nullptr;
     hipError_t e = hipHostMalloc(&q, bucket, hipHostMallocPortable | hipHostMallocMapped);
-    if (e != hipSuccess) return fail(SIFTMI_ENOMEM, "hipHostMalloc(%zu): %s", bucket, hipGetErrorString(e));
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SIFTMI_ENOMEM, "hipHostMalloc(%zu): %s", bucket, hipGetErrorString(e)); }
     std::lock_guard<std::mutex> g(hp.mu);
-    hp.live[q] = bucket;
+    hp.live[q] = bucket; hp.live_bytes += bucket;
     *out = q;
     return SIFTMI_OK;
 }
 
+// A block returns to the pool; nothing is handed back to the driver here (hipHostFree synchronises the device, and this runs
+// from a Python destructor): a block beyond what its bucket keeps (8 blocks, 3 from 16 MiB on) is set aside and released by
+// the next siftmi_host_alloc, or by siftmi_host_pool_trim.
 int siftmi_host_free(void *ptr) {
     if (!ptr) return SIFTMI_OK;
     HostPool &hp = host_pool();
+    std::lock_guard<std::mutex> g(hp.mu);
+    auto it = hp.live.find(ptr);
+    if (it == hp.live.end()) return fail(SIFTMI_EINVAL, "not a siftmi_host_alloc block");
+    const size_t bucket = it->second;
+    hp.live.erase(it);
+    hp.live_bytes -= bucket;
+    std::vector<void *> &v = hp.spare[bucket];
+    if (v.size() < (bucket >= ((size_t)16 << 20) ? (size_t)3 : HostPool::kKeep)) { v.push_back(ptr); hp.spare_bytes += bucket; }
+    else hp.trash.push_back(ptr);
+    return SIFTMI_OK;
+}
+
+// Release spare blocks until at most `keep_bytes` of them remain (0: all).  Synchronises the device (hipHostFree).
+int siftmi_host_pool_trim(int64_t keep_bytes) {
+    HostPool &hp = host_pool();
+    std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> g(hp.mu);
-        auto it = hp.live.find(ptr);
-        if (it == hp.live.end()) return fail(SIFTMI_EINVAL, "not a siftmi_host_alloc block");
-        const size_t bucket = it->second;
-        hp.live.erase(it);
-        std::vector<void *> &v = hp.spare[bucket];
-        // (large blocks -- whole result images, record lists of dense frames -- are kept three deep: enough for a caller that
-        // drops each result before the next call, without parking hundreds of MB of page-locked memory)
-        if (v.size() < (bucket >= ((size_t)16 << 20) ? (size_t)3 : HostPool::kKeep)) { v.push_back(ptr); return SIFTMI_OK; }
+        drop.swap(hp.trash);
+        for (auto &kv : hp.spare)
+            while ((int64_t)hp.spare_bytes > keep_bytes && !kv.second.empty()) {
+                drop.push_back(kv.second.back()); kv.second.pop_back(); hp.spare_bytes -= kv.first;
+            }
     }
-    (void)hipHostFree(ptr);
+    for (void *q : drop) (void)hipHostFree(q);
     return SIFTMI_OK;
 }
 

@@ -56,6 +56,24 @@ class _DeviceRecords(object):
         self.__cuda_array_interface__ = {"shape": (n * 144,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
 
 
+class _StageProfile(object):
+    __slots__ = ("start", "end")
+
+    def __init__(self, ns):
+        self.start, self.end = 0, int(ns)
+
+
+class StageEvent(object):
+    """What ``SiftPlan.events`` holds beside a label under ``profile=True``: the reference appends ``(label, pyopencl event)``
+    pairs (plan.py:331, 455, 522, 594) whose callers read ``evt.profile.end - evt.profile.start`` in nanoseconds
+    (plan.py:838-846); this carries the hipEvent time of the stage the same way (``start`` is 0), and ``ms``."""
+    __slots__ = ("profile", "ms")
+
+    def __init__(self, ms):
+        self.ms = float(ms)
+        self.profile = _StageProfile(round(1e6 * self.ms))
+
+
 class SiftPlan(object):
     """Plan to compute SIFT keypoints of images of one shape and type.
 
@@ -322,6 +340,8 @@ class SiftPlan(object):
             if self.overflow:
                 logger.warning("Keypoint counter overflow: an octave needs more than %s entries, result cut to that per octave", self.kpsize)
             output = output.view(numpy.recarray)
+            if self._profile_level == 2:         # (label, event) per stage of this call, as the reference's plan.events
+                self.events = [(label, StageEvent(ms)) for label, ms in self._profile_lines()]
             del keep
             if logger.isEnabledFor(logging.INFO):
                 logger.info("Execution time: %.3fms" % (1000 * (time.time() - t0)))
@@ -407,7 +427,8 @@ class SiftPlan(object):
         """If profiling is on, print the device time of every stage of the last call."""
         t = orient = descr = 0.0
         if self.profile:
-            for label, et in self._profile_lines():
+            for label, evt in (self.events or [(l, StageEvent(ms)) for l, ms in self._profile_lines()]):
+                et = 1e-6 * (evt.profile.end - evt.profile.start)          # as plan.py:838-839
                 print("%50s:\t%.3fms" % (label, et))
                 t += et
                 if "orient" in label:
@@ -420,6 +441,7 @@ class SiftPlan(object):
         print("%50s:\t%.3fms" % ("Total Descriptors", descr))
 
     def reset_timer(self):
+        """plan.py:849-855: forget the events of the last call"""
         with self._sem:
             self.events = []
 

@@ -408,6 +408,16 @@ def test_keypoints_octave_limit_and_profile(siftlib, oracle):
     kt = plan.kernel_times()
     assert kt["total_ms"] > 0 and kt["blur_launches"] == 16 and kt["blur_ms"] <= kt["total_ms"]
     assert plan.minmax() == (float(img.min()), float(img.max()))
+    # plan.events as the reference fills it under profile=True (plan.py:331, 455, 522, 594): (label, event) per stage of the
+    # last call, event.profile.end - event.profile.start in nanoseconds (plan.py:838-839)
+    labels = [l for l, _ in plan.events]
+    assert len(plan.events) >= 16 + 6 and any("Blur" in l for l in labels) and any("descriptors" in l for l in labels)
+    total_ns = sum(e.profile.end - e.profile.start for _, e in plan.events)
+    assert 0 < total_ns * 1e-6 < 50.0
+    plan.log_profile()
+    plan.reset_timer()
+    assert plan.events == []
+    assert sp.SiftPlan(template=img).keypoints(img) is not None and sp.SiftPlan(template=img).events == []
 
 
 def test_keypoints_integer_and_device_inputs(siftlib, oracle):

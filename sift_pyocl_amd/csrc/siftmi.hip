@@ -37,9 +37,11 @@ namespace {
 
 thread_local std::string g_err;
 
-// Events that order one stream of a plan behind another ON THE SAME DEVICE: no timing, and no system-scope fence when they are
-// recorded (the kernels' own agent-scope release / acquire at their boundaries is what the consumers need; nothing the host or
-// another device reads is ordered by these events -- results are waited for through the streams themselves).
+// Events that order one stream of a plan behind another ON THE SAME DEVICE, kernel to kernel: no timing, and no system-scope fence when they are
+// recorded.  INVARIANT: producer and consumer of such an event are kernels on this device (ev_pyr, ev_p3, ev_maps0).  Anything whose
+// consumer is a DMA copy, the host or another device -- the upload ring's events, the events bracketing a profile -- uses plain events.
+// (The kernels' own agent-scope release / acquire at their boundaries is what the consumers need; nothing the host or another
+// device reads is ordered by these events -- results are waited for through the streams themselves.)
 #ifndef SIFT_SYNC_EVENT
 #define SIFT_SYNC_EVENT (hipEventDisableTiming | hipEventDisableSystemFence)
 #endif
@@ -1629,7 +1631,7 @@ int siftmi_batch_info(const siftmi_batch *b, int32_t *lanes, int64_t *bytes_allo
     if (!b) return fail(SIFTMI_EINVAL, "null batch");
     if (lanes) *lanes = (int32_t)b->lanes.size();
     if (bytes_allocated) {
-        int64_t t = (int64_t)b->arena_cap;
+        int64_t t = (int64_t)b->arena_cap + (int64_t)(b->ring.size() * b->ring_bytes);
         for (const siftmi_plan *p : b->lanes) t += p->bytes;
         *bytes_allocated = t;
     }
@@ -1726,6 +1728,9 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     if (!b || (n_images > 0 && !images) || !counts || !offsets || !total_parked) return fail(SIFTMI_EINVAL, "null argument");
     if (n_images < 0) return fail(SIFTMI_EINVAL, "negative image count");
     if ((host_outs == nullptr) != (host_caps == nullptr)) return fail(SIFTMI_EINVAL, "host_outs and host_caps go together");
+    if (dtype_size(image_dtype) == 0) return fail(SIFTMI_EINVAL, "invalid input format (%d)", image_dtype);
+    if (!b->lanes.empty() && image_dtype != b->lanes[0]->dtype && image_dtype != SIFTMI_F32)
+        return fail(SIFTMI_EINVAL, "image dtype %d is neither the plan's (%d) nor float32", image_dtype, b->lanes[0]->dtype);
     HIPCHK(hipSetDevice(b->device));
     batch_drain(b);                      // no-op unless the previous call failed half way
     if (overflow) *overflow = 0;
@@ -1737,30 +1742,35 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
     b->cur_images = images; b->cur_dtype = image_dtype; b->cur_is_device = images_are_device;
     b->counts.assign((size_t)n_images, 0);
     b->offsets.assign((size_t)n_images, 0);
-    if (images_are_device) HIPCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams
     const size_t L = b->lanes.size();
     int rc = SIFTMI_OK;
+    // (from here on an error must not return at once: the lanes and the copy stream may be reading the caller's frames or
+    // writing its arrays -- every failure goes through the drain at the end)
+#define BATCHCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess && !rc) rc = fail(e_ == hipErrorOutOfMemory ? SIFTMI_ENOMEM : SIFTMI_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+    if (images_are_device) BATCHCHK(hipDeviceSynchronize());   // once per batch: order after the caller's streams
     const bool htime = L > 0 && b->lanes[0]->opt.host_timing;   // diagnostic: where the host thread spends the batch
     auto tnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_retire = 0, t_enqueue = 0;
     // host frames go through the upload ring (see siftmi_batch)
     const bool staged = !images_are_device && n_images > 0 && L > 0;
     const size_t frame_bytes = staged ? (size_t)b->lanes[0]->H * b->lanes[0]->W * dtype_size(image_dtype) : 0;
-    if (staged) {
+    if (staged && !rc) {
         if (b->ring_bytes < frame_bytes || b->ring.size() != L + 1) {
-            HIPCHK(hipDeviceSynchronize());
+            BATCHCHK(hipDeviceSynchronize());
             for (void *q : b->ring) hipFree(q);
             b->ring.clear(); b->ring_bytes = 0;
-            for (size_t k = 0; k < L + 1; k++) {
+            for (size_t k = 0; k < L + 1 && !rc; k++) {
                 void *q = nullptr;
-                hipError_t e = hipMalloc(&q, frame_bytes);
-                if (e != hipSuccess) { b->host_outs = nullptr; b->host_caps = nullptr; b->cur_images = nullptr; return fail(SIFTMI_ENOMEM, "hipMalloc(%zu): %s", frame_bytes, hipGetErrorString(e)); }
-                b->ring.push_back(q);
+                BATCHCHK(hipMalloc(&q, frame_bytes));
+                if (!rc) b->ring.push_back(q);
             }
-            b->ring_bytes = frame_bytes;
+            if (!rc) b->ring_bytes = frame_bytes;          // (counted by siftmi_batch_info: L + 1 staged frames in HBM)
+            else { for (void *q : b->ring) hipFree(q); b->ring.clear(); }
         }
-        while (b->ring_ev.size() < L + 1) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); b->ring_ev.push_back(e); }
-        if (!b->copy_stream) HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+        // (the ring's events order a DMA copy before kernels of another stream: plain events, WITH their system-scope fence --
+        // unlike the plan's kernel-to-kernel events, SIFT_SYNC_EVENT)
+        while (b->ring_ev.size() < L + 1 && !rc) { hipEvent_t e = nullptr; BATCHCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); if (!rc) b->ring_ev.push_back(e); }
+        if (!b->copy_stream && !rc) BATCHCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     }
     auto upload = [&](int i) -> int {             // frame i -> ring slot i % (L + 1); the slot's previous frame (i - L - 1) has retired
         if (!images[i]) return fail(SIFTMI_EINVAL, "null image %d", i);
@@ -1769,7 +1779,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
         HIPCHK(hipEventRecord(b->ring_ev[k], b->copy_stream));
         return SIFTMI_OK;
     };
-    if (staged) rc = upload(0);
+    if (staged && !rc) rc = upload(0);
     for (int i = 0; i < n_images && !rc; i++) {
         if (!images[i]) { rc = fail(SIFTMI_EINVAL, "null image %d", i); break; }
         const size_t l = (size_t)i % L;
@@ -1781,8 +1791,8 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
             // frame i - L has just retired, so has every earlier one: slot (i + 1) % (L + 1), last used by frame i - L, is free
             if (i + 1 < n_images && (rc = upload(i + 1))) break;
             const size_t k = (size_t)i % (L + 1);
-            HIPCHK(hipStreamWaitEvent(b->lanes[l]->stream, b->ring_ev[k], 0));
-            rc = plan_enqueue(b->lanes[l], b->ring[k], image_dtype, 1, false);
+            BATCHCHK(hipStreamWaitEvent(b->lanes[l]->stream, b->ring_ev[k], 0));
+            if (!rc) rc = plan_enqueue(b->lanes[l], b->ring[k], image_dtype, 1, false);
         } else
         rc = plan_enqueue(b->lanes[l], images[i], image_dtype, images_are_device, false);
         if (htime) { b->lanes[l]->opt.host_timing = 1; t_retire += tb - ta; t_enqueue += tnow() - tb; }
@@ -1799,6 +1809,7 @@ int siftmi_batch_keypoints_into(siftmi_batch *b, const void *const *images, int3
         g_err = keep;
         return rc;
     }
+#undef BATCHCHK
     HIPCHK(hipDeviceSynchronize());                            // the parking copies
     for (int i = 0; i < n_images; i++) { counts[i] = b->counts[(size_t)i]; offsets[i] = b->offsets[(size_t)i]; }
     *total_parked = (int64_t)(b->arena_used / sizeof(KpRecord));

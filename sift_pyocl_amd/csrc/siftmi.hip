@@ -131,6 +131,18 @@ struct Options {
                              // 0.205 / 0.249 ms, 1024^2 0.281 / 0.328, 2048^2 0.450 / 0.508, 4096^2 with 9 / 5 / 4 / 3 octaves 0.943 / 0.956,
                              // 0.852 / 0.868, 0.830 / 0.833, 0.821 / 0.789 (three octaves: two sparse groups each pay a launch chain beside
                              // octave 0's descriptors), 16384^2 10.46 / 10.48; smoothed noise 4096^2 4.45 / 4.38, 2048^2 1.45 / 1.49
+    int early_chain = 2;     // the later octaves' chain starts when plane 3 of octave 0 exists (behind its third blur: octave 1's plane 0 rides on
+                             // that launch), not behind its fifth: 0 never, 1 always, 2 unless the previous image of the plan was keypoint-rich
+                             // (one keypoint per `maps_density` pixels of octave 0).  Round 3 measured this slower (0.854 -> 0.894 ms): the later
+                             // octaves' detection then still had to wait for octave 0's orientation pass (one shared list).  With a list per
+                             // group the chain runs through: its pyramids share the chip with octave 0's last two blurs instead of with its
+                             // descriptor launch, whose workgroups starve them of registers (blur_hv 21 / 27 taps on a 1024^2 plane: 83 / 115 us
+                             // beside 768 descriptor workgroups, 10 / 11 alone).  Interleaved A/B, early against late: 512^2 0.194 / 0.205 ms,
+                             // 1024^2 0.259 / 0.281, 2048^2 0.425 / 0.453 (3 octaves: 0.367 / 0.388), 4096^2 with 9 / 4 octaves 0.891-0.900 /
+                             // 0.926, 0.817 / 0.841, with 3 (the headline) 0.785-0.799 / 0.789-0.794 (hence: not on >= 8 Mpixel frames of three
+                             // octaves); smoothed noise 4096^2 4.42 / 4.26 (hence the density rule), 2048^2 1.39 / 1.38, 1024^2 0.576 / 0.596
+    int desc_early_blocks = 704;   // descriptor workgroups of a small octave 0 when the later octaves started early (they are nearly done by
+                                   // then: 576 leaves room nobody needs, 960 starves what is left; 640 / 704 / 768 / 832: 0.797 / 0.785 / 0.788-0.799 / 0.801)
     int fused_refine = 1;    // detection and refinement in one launch: 0 never, 1 planes below 1400^2, 2 every plane
     int fused_shrink = 1;    // octave hand-off inside the blur launch that writes plane 3 (512^2 frame -4 %, 2048^2 -4 %, 4096^2 +-0)
     int ori_team = 1024;     // groups with fewer refined keypoints than this: a workgroup per keypoint in the orientation launch (0: never)
@@ -185,11 +197,13 @@ struct siftmi_plan {
     float *planes = nullptr;      // all octaves' blur planes: octave o, scale s at plane(o, s)
     std::vector<size_t> oct_off;  // float offset of octave o's first plane
     float *tmp = nullptr;         // generic two-pass blur only (tap counts without a fused kernel): intermediate plane
+    float *tmp_later = nullptr;   // ... of octave 1's chain, which may run beside octave 0's last two blurs (early_chain),
     float *tmp_below = nullptr;   // ... of the chain of the octaves below octave 1, which runs beside octave 1's last blurs
     hipStream_t stream2 = nullptr;            // octave 0's gradient maps; the octaves below octave 1 (pyramids, detection, the tail launch, description)
     hipStream_t stream3 = nullptr;            // octave 1 (pyramid, detection, description) -- or every later octave when they form one chain
     int64_t acc_calls = 0, acc_b0_launches = 0;   // running totals of the light profile (siftmi_plan_profile_totals)
     double acc_total_ms = 0, acc_b0_ms = 0, acc_b0_pixels = 0;
+    hipEvent_t ev_early = nullptr;
     hipEvent_t ev_p3 = nullptr;               // plane 3 of octave 1 (and octave 2's plane 0) exist: the chain of the octaves below starts there
     std::vector<hipEvent_t> ev_pyr;           // pyramid of octave o complete (recorded on `stream`)
     bool overlap = true;
@@ -205,6 +219,7 @@ struct siftmi_plan {
     size_t planes_floats = 0;
     bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves (groups 1 and 2)
     // the image being enqueued / waited for
+    bool early_cur = false;                   // the later octaves' chain started at plane 3 of octave 0
     bool fork_cur = false;                    // octave 1 is a group of its own (1), the octaves below it group 2; else all later octaves in group 2
     unsigned groups_cur = 0;                  // bit g: group g has launches in this image
     int tail_first_cur = 0;                   // first octave of the tail launch (n_oct: none)
@@ -403,7 +418,10 @@ bool launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, cons
     if (!st) st = p->stream;
     const int r = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm, half)
                        : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm, half);
-    if (!r) launch_blur_generic(st, in, out, (st == p->stream2 && p->tmp_below) ? p->tmp_below : p->tmp, W, H, t, p->mm, norm);
+    if (!r) {       // one intermediate plane per stream that builds pyramids: the chains run beside one another
+        float *tmp = (st == p->stream2 && p->tmp_below) ? p->tmp_below : ((st == p->stream3 && p->tmp_later) ? p->tmp_later : p->tmp);
+        launch_blur_generic(st, in, out, tmp, W, H, t, p->mm, norm);
+    }
     return r == 2;
 }
 
@@ -696,7 +714,7 @@ void launch_descriptor_group(siftmi_plan *p, int group, hipStream_t st) {
     const int desc_pad = p->opt.desc_pad > 0 ? p->opt.desc_pad : 0;
     // a small group of octave 0 of a LARGE frame leaves room for the later octaves' chain, which ends such an image (4096^2
     // headline -2.2 %, 4096^2 with every octave -2.5 %); on a 1024^2 frame that chain is short and the same cut costs 2 %
-    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? p->opt.desc_small_blocks : desc_blocks;
+    const int small_blocks = (group == 0 && p->n_oct > 1 && march_plane(p->ow[0], p->oh[0])) ? (p->early_cur ? p->opt.desc_early_blocks : p->opt.desc_small_blocks) : desc_blocks;
     const int ocap = (int)G.cap_out, rcap = (int)std::min<int64_t>(p->cap_rec, 0x7fffffff);
     if (p->desc_rows && !p->opt.desc_stream) {
         // one launch, two forms: the count of the group (known on the device only) picks the wave-per-keypoint form
@@ -834,6 +852,7 @@ int siftmi_plan_create(int32_t height, int32_t width, int32_t in_dtype, int32_t 
         else p->ev_pyr.push_back(e);
     }
     if (!rc) rc = p->alloc(&p->tmp, N * sizeof(float));
+    if (!rc && p->n_oct > 1) rc = p->alloc(&p->tmp_later, (size_t)p->ow[1] * p->oh[1] * sizeof(float));
     if (!rc && p->n_oct > 2) rc = p->alloc(&p->tmp_below, (size_t)p->ow[2] * p->oh[2] * sizeof(float));
     if (!rc) rc = p->alloc(&p->raw, N * (dtype_size(in_dtype) > 4 ? dtype_size(in_dtype) : 4));
     if (!rc && in_dtype != SIFTMI_F32) rc = p->alloc(&p->conv, N * sizeof(float));
@@ -870,6 +889,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
     if (p->stream3) { hipStreamSynchronize(p->stream3); hipStreamDestroy(p->stream3); }
     if (p->ev_p3) hipEventDestroy(p->ev_p3);
+    if (p->ev_early) hipEventDestroy(p->ev_early);
     if (p->ev_maps0) hipEventDestroy(p->ev_maps0);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
     for (void *q : p->allocs) hipFree(q);
@@ -950,6 +970,8 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "maps") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "maps must be 0 (never), 1 (always) or 2 (by the previous image)"); o.maps = v; }
     else if (n == "maps_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_blocks must be >= 1"); o.maps_blocks = v; }
     else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
+    else if (n == "early_chain") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "early_chain must be 0 (never), 1 (always) or 2 (unless the previous image was keypoint-rich)"); o.early_chain = v; }
+    else if (n == "desc_early_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_early_blocks must be >= 1"); o.desc_early_blocks = v; }
     else if (n == "fork") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fork must be 0 (never), 1 (always) or 2 (frames of five octaves and more)"); o.fork = v; }
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
@@ -1124,6 +1146,15 @@ int enqueue_body(siftmi_plan *p) {
     p->fork_cur = fork;
     hipStream_t later = two ? p->stream3 : p->stream;       // octave 1's chain (every later octave's without the fork)
     hipStream_t below = fork ? p->stream2 : later;          // the chain of the octaves below octave 1
+    // ... starts at plane 3 of octave 0 (option "early_chain"): needs the fused hand-off (octave 1's plane 0 written by octave 0's third blur)
+    bool early = two && p->opt.early_chain && p->n_oct > 1 && p->profile <= 1 && p->opt.fused_shrink && tail_first != 1;
+    if (early && p->opt.early_chain == 2) {
+        const long long px0 = (long long)p->ow[0] * p->oh[0];
+        // not on keypoint-rich frames (+4 % at 4096^2), and not where it brings nothing: a frame of at least 8 Mpixel with three
+        // octaves (the later octaves' chain is short there: +-1 %, and octave 0's last two blurs would share the chip for nothing)
+        early = (long long)p->last_group0 * p->opt.maps_density < px0 && (p->n_oct >= 4 || px0 < (8ll << 20));
+    }
+    p->early_cur = early;
     bool handed[SIFT_MAX_OCTAVES + 1] = {false};   // plane 0 of the octave was written by the blur launch of the octave above
     hipEvent_t pyr0_done = nullptr;            // light profile: the blur bracket's closing event stands in for ev_pyr[0]
     int slot = 0;                              // read-back blocks used so far (one per ending stream)
@@ -1153,6 +1184,10 @@ int enqueue_body(siftmi_plan *p) {
                 Scope sc(p, lab, true, (double)W * H, pyr, p->profile > 1 ? oct : -2);      // (light profile: octave 0 is inside the open bracket, the others are not timed)
                 if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
             }
+            if (s == 2 && oct == 0 && early) {
+                if (!p->ev_early) HIPCHK(hipEventCreateWithFlags(&p->ev_early, SIFT_SYNC_EVENT));
+                HIPCHK(hipEventRecord(p->ev_early, pyr));
+            }
             if (s == 2 && oct == 1 && fork) {
                 // plane 3 of octave 1 and plane 0 of octave 2 exist (or will be shrunk from it): the chain below starts here
                 HIPCHK(hipEventRecord(p->ev_p3, pyr));
@@ -1169,6 +1204,7 @@ int enqueue_body(siftmi_plan *p) {
         return SIFTMI_OK;
     };
     auto wait_pyr0 = [&](hipStream_t st) { return hipStreamWaitEvent(st, pyr0_done ? pyr0_done : p->ev_pyr[0], 0); };
+    auto wait_later = [&](hipStream_t st) { return early ? hipStreamWaitEvent(st, p->ev_early, 0) : wait_pyr0(st); };
     int rc = SIFTMI_OK;
     if (p->n_oct > 0) {
         // ---- octave 0 (tail_first_octave never takes it: the tail launch starts from plane 3 of an octave above)
@@ -1188,7 +1224,7 @@ int enqueue_body(siftmi_plan *p) {
     }
     if (p->n_oct > 1) {
         // ---- the later octaves: octave 1 (group 1 when the chain forks, else part of group 2), then the octaves below (group 2)
-        if (two) HIPCHK(wait_pyr0(later));
+        if (two) HIPCHK(wait_later(later));
         for (int oct = 1; oct < p->n_oct; oct++) {
             hipStream_t st = (oct == 1) ? later : below;
             if (oct == tail_first) {   // this octave and every later one: one launch (k_tail.hpp)

@@ -49,6 +49,6 @@ def test_fuzz_small_shapes(siftlib, oracle):
         if it % 4 == 2:
             plan.set_option("overlap", 0)
         if it % 4 == 3:
-            plan.set_option("fork", 0)
+            plan.set_option("fork", 0); plan.set_option("early_chain", 0)
         assert_same_keypoints(plan.keypoints(img), want, "small fuzz %d %dx%d %s" % (it, H, W, np.dtype(dt).name))
         assert_same_keypoints(plan.keypoints(img), want, "small fuzz %d, second call" % it)

@@ -226,8 +226,10 @@ def leg_c3(sp, torch, local_rank, size=16384, steps=3):
                         % (size, size, n_oct)}
 
 
-def leg_c4(sp, torch, local_rank, steps=3):
-    """C4 on one GPU: the 64 x 2048^2 batch through a BatchPlan (16 lanes), records left in HBM as the exchange wants them."""
+def leg_c4(sp, torch, local_rank, steps=3, keep=None):
+    """C4 on one GPU: the 64 x 2048^2 batch through a BatchPlan (16 lanes), records left in HBM as the exchange wants them.
+    With `keep` (a list) the plans and frames are handed to the caller instead of being freed here: freeing 16 plans idles
+    the GPU for longer than its clocks stay up."""
     frames = [torch.from_numpy(make_image(1000 + i, C4_SIZE)).cuda() for i in range(C4_FRAMES)]
     bp = sp.BatchPlan(shape=(C4_SIZE, C4_SIZE), dtype=np.float32, device=local_rank, profile="light")
     n_oct = int(bp.octave_max)
@@ -246,8 +248,11 @@ def leg_c4(sp, torch, local_rank, steps=3):
     balg = C4_FRAMES * bytes_alg(C4_SIZE, C4_SIZE, n_oct, nk / C4_FRAMES)
     blur_gbs = (8.0 * blur["blur0_pixels"] / 1e9) / (blur["blur0_ms"] / 1e3) if blur and blur["blur0_ms"] > 0 else 0.0
     lanes = bp.lanes
-    del bp, frames
-    torch.cuda.empty_cache()
+    if keep is not None:
+        keep.append((bp, frames, rec))
+    else:
+        del bp, frames
+        torch.cuda.empty_cache()
     return {"ms_per_batch": round(1e3 * el, 3), "ms_per_frame": round(1e3 * el / C4_FRAMES, 4),
             "value": round(C4_FRAMES * C4_SIZE * C4_SIZE / 1e6 / el, 1), "unit": "Mpix/s", "frames": C4_FRAMES, "lanes": lanes,
             "octaves": n_oct, "keypoints": nk, "keypoints_per_s": round(nk / el, 1),
@@ -262,30 +267,9 @@ def leg_c4(sp, torch, local_rank, steps=3):
                         % (C4_FRAMES, C4_SIZE, C4_SIZE, lanes)}
 
 
-def extras(sp, torch, size, n_oct, local_rank):
+def extras(sp, torch, size, n_oct, local_rank, keep=None):
     """Measurements beside the headline, N = 1 only, outside the timed region and never part of `value`."""
     out = {}
-    # (1) the pipelined path (BatchPlan, SURVEY 8f-4): what a caller with a stack of frames gets from one GPU
-    try:
-        frames = [torch.from_numpy(make_image(i, size)).cuda() for i in range(8)] * 2
-        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct, lanes=2)
-        bp.keypoints_batch(frames)
-        torch.cuda.synchronize()
-        times = []
-        for _ in range(4):
-            t1 = time.perf_counter()
-            res = bp.keypoints_batch(frames)
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t1)
-        tb = sorted(times)[len(times) // 2]
-        out["pipelined"] = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s",
-                            "ms_per_frame": round(1e3 * tb / len(frames), 4), "frames_per_call": len(frames), "lanes": 2,
-                            "keypoints": int(sum(len(r) for r in res)),
-                            "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans; every frame bit-identical "
-                                    "to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
-        del bp, frames
-    except Exception as exc:
-        out["pipelined"] = {"error": str(exc)[:200]}
     # (2) host-to-host: the reference API takes host numpy arrays (plan.py:450-456); PCIe-inclusive, never `value`
     try:
         plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct)
@@ -354,17 +338,6 @@ def extras(sp, torch, size, n_oct, local_rank):
         del hframes
     except Exception as exc:
         out["pipelined_host"] = {"error": str(exc)[:200]}
-    # (2d) BASELINE.json configs[2]: SiftPlan 16384 x 16384 fp32, every octave -- the configuration whose planes (1 GiB each)
-    #      do not fit the 256 MiB Infinity Cache, i.e. where the HBM roofline is about HBM
-    try:
-        out["c3_16384"] = leg_c3(sp, torch, local_rank)
-    except Exception as exc:
-        out["c3_16384"] = {"error": str(exc)[:200]}
-    # (2e) BASELINE.json configs[3] on this one GPU: 64 frames of 2048 x 2048 through a BatchPlan
-    try:
-        out["c4_one_gpu"] = leg_c4(sp, torch, local_rank)
-    except Exception as exc:
-        out["c4_one_gpu"] = {"error": str(exc)[:200]}
     # (3) MatchPlan, BASELINE.json configs[4]: 100k x 100k 128-D uint8 descriptors, L1 + ratio test as the reference
     try:
         n = 100000
@@ -388,6 +361,42 @@ def extras(sp, torch, size, n_oct, local_rank):
                              "note": "brute-force L1 + 0.73^2 ratio test, both lists resident in HBM"}
     except Exception as exc:
         out["match_100k"] = {"error": str(exc)[:200]}
+    # (2d) BASELINE.json configs[2]: SiftPlan 16384 x 16384 fp32, every octave -- the configuration whose planes (1 GiB each)
+    #      do not fit the 256 MiB Infinity Cache, i.e. where the HBM roofline is about HBM
+    try:
+        out["c3_16384"] = leg_c3(sp, torch, local_rank)
+    except Exception as exc:
+        out["c3_16384"] = {"error": str(exc)[:200]}
+    # (2e) BASELINE.json configs[3] on this one GPU: 64 frames of 2048 x 2048 through a BatchPlan
+    try:
+        out["c4_one_gpu"] = leg_c4(sp, torch, local_rank)
+    except Exception as exc:
+        out["c4_one_gpu"] = {"error": str(exc)[:200]}
+    # (4) the pipelined path (BatchPlan): what a caller with a stack of frames gets from one GPU (last: the same
+    #     kernels on the same frame size as the headline, whose warm-up follows directly)
+    try:
+        frames = [torch.from_numpy(make_image(i, size)).cuda() for i in range(8)] * 2
+        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct, lanes=2)
+        for _ in range(2):
+            bp.keypoints_batch(frames)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            res = bp.keypoints_batch(frames)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+        tb = sorted(times)[len(times) // 2]
+        out["pipelined"] = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s",
+                            "ms_per_frame": round(1e3 * tb / len(frames), 4), "frames_per_call": len(frames), "lanes": 2,
+                            "keypoints": int(sum(len(r) for r in res)),
+                            "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans; every frame bit-identical "
+                                    "to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
+        if keep is not None:
+            keep.append((bp, frames, res))      # freed by the caller after its timed region (freeing plans idles the GPU)
+        del bp, frames
+    except Exception as exc:
+        out["pipelined"] = {"error": str(exc)[:200]}
     return out
 
 
@@ -453,6 +462,9 @@ def main():
         return t if t.device == xdev else t.to(xdev)
 
     result = {}
+    extra = {}
+    keepalive = []          # what the last leg before the timed region allocated: freed after the region, not before it
+    order = "W warm-up + K timed steps first"
     if c4:
         # ---------------------------------------------------------------- C4: 64 x 2048^2 sharded over the ranks
         mine = shard_indices(C4_FRAMES, rank, world)
@@ -521,8 +533,21 @@ def main():
             kept["counts"], kept["used"] = [], 0
             return out, used
 
+        # The legs beside the headline run FIRST (N = 1): they are not part of any timed step either way, and the W warm-up
+        # + K timed steps that follow then start from a GPU at its sustained clocks instead of from seconds of idle time
+        # (tools/dev/ramp.py: after 0.2 ... 2 s of idle the first ~25 calls run 0.92, 0.85, 0.83, 0.81, 0.80 ms in groups of
+        # five before the 0.79 of the steady state; rounds 1-4 ran the legs after the timed region and their lines carry that
+        # ramp: compare `steady` across rounds, not `ms_per_step`).  Nothing of the timed region changes.
+        if world == 1 and not args.no_extras:
+            extra = extras(sp, torch, size, n_oct, local_rank, keep=keepalive)
+            order = "legs beside the headline first, then W warm-up + K timed steps, then `steady`, then the CPU baselines"
+        else:
+            order = "W warm-up + K timed steps first"
+        last = None
         for i in range(W):
-            plan.keypoints(dev_images[i % n_img])
+            # held like in the timed loop: the previous result is alive while the next call runs, so the pinned pool serves
+            # two record blocks in rotation (without this the second TIMED step allocated the second block: +0.3 ms once)
+            last = plan.keypoints(dev_images[i % n_img])
             if distributed:
                 keep_records()
         if distributed:
@@ -534,11 +559,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         exchange_ms = exchange_bytes = None
+        marks = []
         for i in range(K):
             last = plan.keypoints(dev_images[i % n_img])
             n_kp += len(last)
             if distributed:
                 keep_records()
+            marks.append(time.perf_counter())
         if distributed:
             torch.cuda.synchronize()
             te = time.perf_counter()
@@ -551,6 +578,8 @@ def main():
         # hipEvent times of the K timed calls (the library sums them as the calls complete: one read-out, after the region)
         t = plan.profile_totals(reset=True)
         assert t["calls"] == K
+        if os.environ.get("BENCH_STEP_TIMES"):
+            print("step ms:", " ".join("%.3f" % (1e3 * (b - a)) for a, b in zip([t0] + marks[:-1], marks)), file=sys.stderr)
         tot_ms = t["total_ms"]; b0_ms = t["blur0_ms"]; b0_px = t["blur0_pixels"]; b0_launches = t["blur0_launches"]
         total_kp = n_kp
         # beside `value`: the same step over a window long enough for the clocks to settle (the first dozen calls after an
@@ -565,6 +594,7 @@ def main():
             torch.cuda.synchronize()
             steady = {"ms_per_step_steady": round(1e3 * (time.perf_counter() - t1) / ns, 4), "steps": ns,
                       "note": "same call, %d further steps right after the timed region" % ns}
+        keepalive.clear()
         units = world * K * size * size / 1e6
         workload = ("SiftPlan %dx%d fp32 uniform white noise (numpy default_rng(seed).random), %d octaves x 3 scales, input "
                     "resident in HBM, records returned to host" % (size, size, n_oct))
@@ -580,11 +610,6 @@ def main():
             tk = torch.tensor([float(total_kp)], dtype=torch.float64, device=xdev)
             dist.all_reduce(tk, op=dist.ReduceOp.SUM)
             total_kp = float(tk.item())
-
-    extra = {}
-    if world == 1 and not args.no_extras and not c4:
-        del plan
-        extra = extras(sp, torch, size, n_oct, local_rank)
 
     if rank == 0:
         out = {
@@ -651,6 +676,7 @@ def main():
                 out["roofline_valu"] = rv
         if kt is not None and kt.get("steady"):
             out["steady"] = kt["steady"]
+        out["order"] = order
         out.update(extra)
         if not args.no_cpu_baseline and world == 1 and not c4:
             out["cpu_baseline"] = cpu_baseline(size, result["n_oct"])

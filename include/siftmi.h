@@ -55,7 +55,9 @@ typedef struct siftmi_params {
     int32_t border_dist;  /* par.BorderDist  (plan.py:630)                                           */
     int32_t octave_max;   /* 0 = every octave (reference behaviour, plan.py:213-224); >0 = extension */
     int32_t pix_per_kp;   /* SiftPlan.PIX_PER_KP: kpsize = H*W / pix_per_kp (plan.py:109, 243)       */
-    int32_t reserved;
+    int32_t double_im_size; /* par.DoubleImSize != 0: the frame counts as blurred by sigma 1.0 instead of 0.5, i.e. the
+                             * initial blur is sqrt(init_sigma^2 - 1) wide (plan.py:254, 297, 534) -- all the reference does
+                             * with that parameter; the image is not resampled                                           */
 } siftmi_params;
 
 typedef struct siftmi_plan siftmi_plan;

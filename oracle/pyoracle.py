@@ -20,14 +20,14 @@ dtype_kp4 = np.dtype((np.float32, 4))
 class Params(C.Structure):
     _fields_ = [("init_sigma", C.c_double), ("peak_thresh", C.c_float), ("edge_thresh0", C.c_float),
                 ("edge_thresh", C.c_float), ("ori_sigma", C.c_float), ("border_dist", C.c_int),
-                ("octave_max", C.c_int), ("pix_per_kp", C.c_int)]
+                ("octave_max", C.c_int), ("pix_per_kp", C.c_int), ("double_im_size", C.c_int)]
 
 
-def default_params(octave_max=0, pix_per_kp=10, init_sigma=1.6):
+def default_params(octave_max=0, pix_per_kp=10, init_sigma=1.6, double_im_size=0):
     """Values of sift-src/param.py:52-79 as plan.py passes them to the kernels."""
     return Params(init_sigma=float(init_sigma), peak_thresh=np.float32(255.0 * 0.04 / 3.0),
                   edge_thresh0=np.float32(0.08), edge_thresh=np.float32(0.06), ori_sigma=np.float32(1.5),
-                  border_dist=5, octave_max=int(octave_max), pix_per_kp=int(pix_per_kp))
+                  border_dist=5, octave_max=int(octave_max), pix_per_kp=int(pix_per_kp), double_im_size=int(bool(double_im_size)))
 
 
 def build(force=False):

@@ -42,6 +42,7 @@ typedef struct {
     int border_dist;     /* par.BorderDist  (param.py:56)  */
     int octave_max;      /* 0 = all octaves (reference behaviour, plan.py:213-224) */
     int pix_per_kp;      /* SiftPlan.PIX_PER_KP (plan.py:109) */
+    int double_im_size;  /* par.DoubleImSize (param.py:53): the input counts as blurred by 1.0 instead of 0.5 (plan.py:254, 297, 534) */
 } so_params;
 
 /* ------------------------------------------------------------------ math exports */
@@ -535,8 +536,9 @@ int so_keypoints(const float *image, int H, int W, const so_params *par, so_reco
     float taps[6][64]; int ntaps[6];
     const double init_sigma = par->init_sigma;
     int have_init = 0;
-    if (init_sigma > 0.5) {                         /* par.DoubleImSize == 0 -> curSigma 0.5 */
-        double s = sqrt(init_sigma * init_sigma - 0.25);
+    const double cur_sigma = par->double_im_size ? 1.0 : 0.5;   /* plan.py:534 */
+    if (init_sigma > cur_sigma) {
+        double s = sqrt(init_sigma * init_sigma - cur_sigma * cur_sigma);
         ntaps[5] = so_kernel_size(s);
         so_gaussian_taps((float)s, ntaps[5], taps[5]);
         have_init = 1;

@@ -19,7 +19,7 @@ DTYPE_CODES = {"float32": 0, "uint8": 1, "uint16": 2, "uint32": 3, "uint64": 4, 
 class Params(C.Structure):
     _fields_ = [("init_sigma", C.c_double), ("peak_thresh", C.c_float), ("edge_thresh0", C.c_float),
                 ("edge_thresh", C.c_float), ("ori_sigma", C.c_float), ("border_dist", C.c_int32),
-                ("octave_max", C.c_int32), ("pix_per_kp", C.c_int32), ("reserved", C.c_int32)]
+                ("octave_max", C.c_int32), ("pix_per_kp", C.c_int32), ("double_im_size", C.c_int32)]
 
 
 def build(force=False):

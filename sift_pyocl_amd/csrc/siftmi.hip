@@ -5,6 +5,7 @@
 // description chain without reading anything back and synchronises once at the end; the
 // reference's host loop (plan.py:596-756) reads a 4-byte counter back >= 18 times per octave.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -285,8 +286,9 @@ int compute_schedule(siftmi_plan *p) {
     // largest descriptor window: sigma <= init_sigma * 2^((3 + 1.5) / 3) (image.cl:354, |offset| <= 1.5), spacing = 3 sigma,
     // R = (int)(1.414 * spacing * 2.5 + 0.5) (keypoints_cpu.cl:57-62); two rows of slack for float rounding
     p->desc_rows = (int)(1.414 * 3.0 * init_sigma * std::pow(2.0, 1.5) * 2.5 + 0.5) + 2 <= SIFT_DESC_MAXRAD;
-    if (init_sigma > 0.5) {   // par.DoubleImSize == 0 -> curSigma = 0.5
-        const double s = std::sqrt(init_sigma * init_sigma - 0.25);
+    const double cur_sigma = p->par.double_im_size ? 1.0 : 0.5;   // par.DoubleImSize (plan.py:534)
+    if (init_sigma > cur_sigma) {
+        const double s = std::sqrt(init_sigma * init_sigma - cur_sigma * cur_sigma);
         p->taps[5].n = kernel_size(s);
         if (p->taps[5].n > 64) return fail(SIFTMI_EINVAL, "init_sigma %g needs %d taps (> 64)", init_sigma, p->taps[5].n);
         int rc = gaussian_taps((float)s, p->taps[5].n, p->taps[5].t);
@@ -310,22 +312,34 @@ int compute_schedule(siftmi_plan *p) {
     return SIFTMI_OK;
 }
 
+// A launch whose completion IS an event (`stop` not null: hipExtLaunchKernelGGL binds the event to the dispatch's own
+// completion signal) instead of a launch followed by hipEventRecord, which puts a barrier packet of its own into the queue:
+// between two 20 us kernels of one stream 2.3 us instead of 3.9 (fence-free event) / 5.3-6.6 (timing event), against 1.3 us
+// with no event at all; a stream waiting for the event starts 7.8 us after the producer's end instead of 9.6 / 11.7
+// (tools/ubench/ext_event.hip).  hipEventElapsedTime between two bound events is end of the first launch -> end of the
+// second (tools/ubench/ext_event2.hip): the light profile's bracket.
+template <typename K, typename... A>
+inline void launch_ev(hipEvent_t stop, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+    if (stop) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, nullptr, stop, 0u, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+
 template <int N, bool NORM, int DT, int TX, int TY, int VR>
-void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, const TapsArg<N> &ta, const uint32_t *mm, float *half) {
+void launch_blur_geom(hipStream_t st, const void *in, float *out, int W, int H, const TapsArg<N> &ta, const uint32_t *mm, float *half, hipEvent_t stop = nullptr) {
     using G = BlurGeom<N, TX, TY>;
     dim3 grid((unsigned)((W + TX - 1) / TX), (unsigned)((H + TY - 1) / TY));
-    hipLaunchKernelGGL((blur_hv_kernel<N, NORM, DT, TX, TY, VR>), grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm, half);
+    launch_ev(stop, blur_hv_kernel<N, NORM, DT, TX, TY, VR>, grid, dim3(256), (size_t)G::LDS_BYTES, st, in, out, W, H, ta, mm, half);
 }
 
 // Tile shape: planes that reach this kernel are narrower than 1024 columns or shorter than 512 rows (larger ones take the
 // marching kernel); on all of them the 32 x 16 tile measured fastest (whole call, MI355X, round 2: 512^2 0.75 / 0.52 / 0.44 ms
 // and 1020^2 0.90 / 0.63 / 0.53 ms for 128x64 / 64x32 / 32x16 tiles).
 template <int N, bool NORM, int DT = 0>
-void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
+void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr, hipEvent_t stop = nullptr) {
     TapsArg<N> ta;
     for (int i = 0; i < N; i++) ta.t[i] = taps[i];
     (void)opt;
-    launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm, half);
+    launch_blur_geom<N, NORM, DT, 32, 16, 4>(st, in, out, W, H, ta, mm, half, stop);
 }
 
 // team form of the marching blur (blur_team_kernel): S sub-blocks per accumulator period, `wgs` workgroups wanted.
@@ -333,7 +347,7 @@ void launch_blur_t(const Options &opt, hipStream_t st, const void *in, float *ou
 // sub-blocks (nblocks - 1 full periods + last_subs sub-blocks), so the workgroup count is the one asked for -- 768 for
 // 27 taps on a 4096^2 plane, 3 per CU -- instead of one quantised by segment heights in multiples of N rows (608: 2.4 per CU).
 template <int N, bool NORM, int S, int DT = 0>
-void launch_team(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs, float *half) {
+void launch_team(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, int wgs, float *half, hipEvent_t stop) {
     using G = March2Geom<N, 128, S>;
     using SS = SubSplit<N, S>;
     TapsArg<N> ta;
@@ -354,17 +368,17 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
     while (covered(b, m) < need) m++;                // m <= S
     const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    hipLaunchKernelGGL((blur_team_kernel<N, NORM, S, DT>), grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
-                       rows_out, ta, mm, half);
+    launch_ev(stop, blur_team_kernel<N, NORM, S, DT>, grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
+              rows_out, ta, mm, half);
 }
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
 // plane (tools/ubench/blur_team.hip: 31 / 38 / 41 / 47 / 65 us against 33 / 43 / 45 / 53 / 73 us for the one-block form of round 1).
 // returns whether `half` (the fused octave hand-off) was written
 template <int N, bool NORM, int DT = 0>
-bool launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr) {
+bool launch_march_t(const Options &opt, hipStream_t st, const void *in, float *out, int W, int H, const float *taps, const uint32_t *mm, float *half = nullptr, hipEvent_t stop = nullptr) {
     constexpr int S = (N <= 15) ? 2 : (N <= 21 ? 3 : 4);
-    launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024, half);
+    launch_team<N, NORM, S, DT>(opt, st, in, out, W, H, taps, mm, N >= 27 ? 768 : 1024, half, stop);
     return half != nullptr;
 }
 
@@ -374,33 +388,33 @@ bool launch_march_t(const Options &opt, hipStream_t st, const void *in, float *o
 inline bool march_plane(int W, int H) { return W >= 1024 && H >= 512 && (int64_t)W * H >= 1400 * 1400; }
 
 template <bool NORM>
-int launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm, float *half = nullptr) {
+int launch_blur_tiled(const Options &opt, hipStream_t st, const float *in, float *out, int W, int H, const Taps &t, const uint32_t *mm, float *half = nullptr, hipEvent_t stop = nullptr) {
     bool symmetric = true;
     for (int i = 0; i < t.n / 2; i++) symmetric = symmetric && (memcmp(&t.t[i], &t.t[t.n - 1 - i], 4) == 0);
     if constexpr (NORM) {
         // The normalising form exists for the default initial kernel only (15 taps, init_sigma = 1.6); any other
         // InitSigma sends its ONE initial blur through the generic two-pass path (return 0).
         if (t.n != 15) return 0;
-        if (march_plane(W, H) && symmetric && opt.march) return launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
-        launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half);
+        if (march_plane(W, H) && symmetric && opt.march) return launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop) ? 2 : 1;
+        launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop);
         return half ? 2 : 1;
     } else {
     if (march_plane(W, H) && symmetric && opt.march) {
         switch (t.n) {
-            case 11: return launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
-            case 15: return launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
-            case 17: return launch_march_t<17, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
-            case 21: return launch_march_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
-            case 27: return launch_march_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half) ? 2 : 1;
+            case 11: return launch_march_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop) ? 2 : 1;
+            case 15: return launch_march_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop) ? 2 : 1;
+            case 17: return launch_march_t<17, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop) ? 2 : 1;
+            case 21: return launch_march_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop) ? 2 : 1;
+            case 27: return launch_march_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop) ? 2 : 1;
             default: break;
         }
     }
     switch (t.n) {
-        case 11: launch_blur_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
-        case 15: launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
-        case 17: launch_blur_t<17, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
-        case 21: launch_blur_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
-        case 27: launch_blur_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half); return half ? 2 : 1;
+        case 11: launch_blur_t<11, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop); return half ? 2 : 1;
+        case 15: launch_blur_t<15, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop); return half ? 2 : 1;
+        case 17: launch_blur_t<17, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop); return half ? 2 : 1;
+        case 21: launch_blur_t<21, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop); return half ? 2 : 1;
+        case 27: launch_blur_t<27, NORM>(opt, st, in, out, W, H, t.t, mm, half, stop); return half ? 2 : 1;
         default: return 0;
     }
     }
@@ -414,13 +428,16 @@ void launch_blur_generic(hipStream_t st, const float *in, float *out, float *tmp
 }
 
 // `half` not null: the launch may also write out[2y][2x] there (the next octave's plane 0); returns whether it did
-bool launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm, hipStream_t st = nullptr, float *half = nullptr) {
+// `stop` not null: the event is complete when the blur is (bound to the launch, launch_ev; recorded behind the two-pass form)
+bool launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm, hipStream_t st = nullptr, float *half = nullptr,
+                 hipEvent_t stop = nullptr) {
     if (!st) st = p->stream;
-    const int r = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm, half)
-                       : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm, half);
+    const int r = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm, half, stop)
+                       : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm, half, stop);
     if (!r) {       // one intermediate plane per stream that builds pyramids: the chains run beside one another
         float *tmp = (st == p->stream2 && p->tmp_below) ? p->tmp_below : ((st == p->stream3 && p->tmp_later) ? p->tmp_later : p->tmp);
         launch_blur_generic(st, in, out, tmp, W, H, t, p->mm, norm);
+        if (stop) (void)hipEventRecord(stop, st);
     }
     return r == 2;
 }
@@ -458,7 +475,9 @@ bool launch_init_blur_dt(const Options &opt, hipStream_t st, const void *in, flo
 
 struct Scope {   // optional hipEvent bracket around one launch (profile=1: blur launches only; 2: every stage)
     siftmi_plan *p; size_t idx = (size_t)-1; hipStream_t st;
-    Scope(siftmi_plan *pl, const char *label, bool is_blur = false, double pixels = 0, hipStream_t s = nullptr, int octave = -1) : p(pl) {
+    bool stop_bound = false;      // the closing event rides on the bracket's last launch (launch_ev): nothing to record at the end
+    // record_start false: the caller binds the opening event to the launch in FRONT of the bracket (its end opens it)
+    Scope(siftmi_plan *pl, const char *label, bool is_blur = false, double pixels = 0, hipStream_t s = nullptr, int octave = -1, bool record_start = true) : p(pl) {
         st = s ? s : p->stream;
         if (!p->profile || (p->profile == 1 && !(is_blur && octave == 0))) return;
         if (p->n_events == p->events.size()) {
@@ -469,9 +488,9 @@ struct Scope {   // optional hipEvent bracket around one launch (profile=1: blur
         idx = p->n_events++;
         Event &e = p->events[idx];
         e.label = label; e.is_blur = is_blur; e.pixels = pixels; e.octave = octave; e.launches = 1;
-        hipEventRecord(e.a, st);
+        if (record_start) hipEventRecord(e.a, st);
     }
-    ~Scope() { if (idx != (size_t)-1) hipEventRecord(p->events[idx].b, st); }
+    ~Scope() { if (idx != (size_t)-1 && !stop_bound) hipEventRecord(p->events[idx].b, st); }
 };
 
 int grid_for(int64_t n, int block, int max_blocks) {
@@ -934,7 +953,7 @@ int siftmi_plan_set_params(siftmi_plan *p, const siftmi_params *params) {
     // shapes stay those of creation and only the detection border follows.
     if (params->border_dist < 1) return fail(SIFTMI_EINVAL, "border_dist must be >= 1");
     HIPCHK(hipSetDevice(p->device));
-    const bool resched = params->init_sigma != p->par.init_sigma;
+    const bool resched = params->init_sigma != p->par.init_sigma || (params->double_im_size != 0) != (p->par.double_im_size != 0);
     p->par = *params;
     return resched ? compute_schedule(p) : SIFTMI_OK;
 }
@@ -1042,29 +1061,32 @@ int plan_enqueue(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t
         f32src = p->conv;
     }
     const int mm_blocks = p->opt.mm_blocks;
+    // light profiling: ONE event pair around the six full-resolution blur launches (initial + five scales of octave 0),
+    // opened by the END of the min/max launch and closed by the end of octave 0's last blur (enqueue_body) -- both events
+    // ride on those launches (launch_ev), no packet of their own sits between two kernels
+    hipEvent_t open_ev = nullptr;
+    if (p->profile == 1 && p->have_init) {
+        Scope *ch = new Scope(p, "Blur octave 0: initial + scales 0-4 (one bracket)", true, 6.0 * (double)N, nullptr, 0, false);
+        if (ch->idx != (size_t)-1) { p->events[ch->idx].launches = 6; open_ev = p->events[ch->idx].a; }
+        p->chain = ch;
+    }
     {
         Scope sc(p, "max_min");
         if (fused_in) {
-            SIFTMI_TYPED_DISPATCH(image_dtype, hipLaunchKernelGGL(minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, mm_blocks)),
-                                                                   dim3(256), 0, p->stream, src, (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes));
+            SIFTMI_TYPED_DISPATCH(image_dtype, launch_ev(open_ev, minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, mm_blocks)),
+                                                         dim3(256), 0, p->stream, src, (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes));
         } else {
             const int mm_threads = p->opt.mm_threads;
-            hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, mm_threads, mm_blocks)), dim3(mm_threads), 0, p->stream, f32src,
-                               (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes);
+            launch_ev(open_ev, minmax_kernel, dim3(grid_for((int64_t)N / 4, mm_threads, mm_blocks)), dim3(mm_threads), 0, p->stream, f32src,
+                      (int64_t)N, p->mm, (uint32_t *)next_cnt, kCntWords, kCntOnes);
         }
     }
     p->cnt_parity ^= 1;          // the pass that resets the other block is in the queue: the next image takes that block
     p->in_flight = true;
     float *base0 = p->plane(0, 0);
     if (p->have_init) {
-        // light profiling: ONE event pair around the six full-resolution blur launches (initial + five scales of
-        // octave 0); it is closed in enqueue_body.  Event records between kernels cost ~4-10 us each.
         Scope *sc = nullptr;
-        if (p->profile == 1) {
-            Scope *ch = new Scope(p, "Blur octave 0: initial + scales 0-4 (one bracket)", true, 6.0 * (double)N, nullptr, 0);
-            if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 6;
-            p->chain = ch;
-        } else sc = new Scope(p, "normalize + initial blur", true, (double)N, nullptr, 0);
+        if (p->profile != 1) sc = new Scope(p, "normalize + initial blur", true, (double)N, nullptr, 0);
         if (fused_in) {
             SIFTMI_TYPED_DISPATCH(image_dtype, launch_init_blur_dt<DT>(p->opt, p->stream, src, base0, p->W, p->H, p->taps[5], p->mm));
         } else {
@@ -1178,29 +1200,35 @@ int enqueue_body(siftmi_plan *p) {
             if (ch->idx != (size_t)-1) p->events[ch->idx].launches = 5;
             p->chain = ch;
         }
+        bool pyr0_bound = false;
         for (int s = 0; s < 5; s++) {
             if (p->profile > 1) snprintf(lab, sizeof lab, "Blur octave %d scale %d (%d taps)", oct, s, p->taps[s].n);
-            {
-                Scope sc(p, lab, true, (double)W * H, pyr, p->profile > 1 ? oct : -2);      // (light profile: octave 0 is inside the open bracket, the others are not timed)
-                if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr)) handed[oct + 1] = true;
-            }
+            // the events other streams (or the light profile) wait for are the END of a blur launch: they ride on it (launch_ev)
+            hipEvent_t done = nullptr;
             if (s == 2 && oct == 0 && early) {
                 if (!p->ev_early) HIPCHK(hipEventCreateWithFlags(&p->ev_early, SIFT_SYNC_EVENT));
-                HIPCHK(hipEventRecord(p->ev_early, pyr));
+                done = p->ev_early;
+            } else if (s == 2 && oct == 1 && fork) {
+                done = p->ev_p3;       // plane 3 of octave 1 and plane 0 of octave 2 exist (or will be shrunk from it): the chain below starts here
+            } else if (s == 4 && oct == 0 && p->profile == 1 && p->chain) {
+                Scope *ch = static_cast<Scope *>(p->chain);
+                if (ch->idx != (size_t)-1) { done = p->events[ch->idx].b; ch->stop_bound = true; }     // closes the light profile's bracket
+            } else if (s == 4 && oct == 0 && p->profile == 0 && two) {
+                done = p->ev_pyr[0]; pyr0_bound = true;
             }
-            if (s == 2 && oct == 1 && fork) {
-                // plane 3 of octave 1 and plane 0 of octave 2 exist (or will be shrunk from it): the chain below starts here
-                HIPCHK(hipEventRecord(p->ev_p3, pyr));
-                HIPCHK(hipStreamWaitEvent(below, p->ev_p3, 0));
+            {
+                Scope sc(p, lab, true, (double)W * H, pyr, p->profile > 1 ? oct : -2);      // (light profile: octave 0 is inside the open bracket, the others are not timed)
+                if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr, done)) handed[oct + 1] = true;
             }
+            if (s == 2 && oct == 1 && fork) HIPCHK(hipStreamWaitEvent(below, p->ev_p3, 0));
         }
         if (oct == 0 && p->profile == 1) {
             Scope *ch = static_cast<Scope *>(p->chain);
             const size_t idx = ch ? ch->idx : (size_t)-1;
-            delete ch; p->chain = nullptr;                  // records the bracket's closing event on `pyr`
+            delete ch; p->chain = nullptr;                  // (the closing event rode on the last blur launch)
             if (idx != (size_t)-1 && two) pyr0_done = p->events[idx].b;   // ... which is also "octave 0's pyramid exists"
         }
-        if (two && oct == 0 && !pyr0_done) HIPCHK(hipEventRecord(p->ev_pyr[0], pyr));
+        if (two && oct == 0 && !pyr0_done && !pyr0_bound) HIPCHK(hipEventRecord(p->ev_pyr[0], pyr));
         return SIFTMI_OK;
     };
     auto wait_pyr0 = [&](hipStream_t st) { return hipStreamWaitEvent(st, pyr0_done ? pyr0_done : p->ev_pyr[0], 0); };

@@ -170,6 +170,9 @@ class SiftPlan(object):
         L = _lib.lib()
         if L.siftmi_device_count() < 1:
             raise RuntimeError("sift_pyocl_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback")
+        #: par.DoubleImSize as the constructor saw it: the reference prepares the initial blur's taps from it here
+        #: (plan.py:297-300) and looks them up again, by sigma, on every call (plan.py:534-539, 585)
+        self._double_im = bool(par.DoubleImSize)
         self._params = self._current_params()
         self._par_key = (par.PeakThresh, par.EdgeThresh1, par.EdgeThresh, par.OriSigma, par.BorderDist, par.DoubleImSize)
         self._create(L)
@@ -214,7 +217,7 @@ class SiftPlan(object):
     def gaussian_sizes(self):
         """[(sigma, taps)] of the initial blur (if any) and of the five per-octave blurs."""
         out = []
-        cur = 1.0 if par.DoubleImSize else 0.5
+        cur = 1.0 if self._double_im else 0.5
         if self._init_sigma > cur:
             s = math.sqrt(self._init_sigma ** 2 - cur ** 2)
             out.append((s, kernel_size(s, True)))
@@ -226,8 +229,13 @@ class SiftPlan(object):
         return out
 
     def _current_params(self):
-        if par.DoubleImSize:
-            raise RuntimeError("par.DoubleImSize is not supported (neither does the reference implement it)")
+        # par.DoubleImSize: all the reference does with it is to count the input as blurred by sigma 1.0 instead of 0.5
+        # (plan.py:254, 297, 534) -- the image is never resampled.  A value that changed since the constructor asks for
+        # an initial blur whose taps the reference has not prepared: its look-up by sigma fails (plan.py:585).
+        dbl = bool(par.DoubleImSize)
+        cur = 1.0 if dbl else 0.5
+        if dbl != self._double_im and self._init_sigma > cur:
+            raise KeyError("gaussian_%s" % math.sqrt(self._init_sigma ** 2 - cur ** 2))
         return _lib.Params(init_sigma=self._init_sigma,
                            peak_thresh=numpy.float32(par.PeakThresh),
                            edge_thresh0=numpy.float32(par.EdgeThresh1),
@@ -235,7 +243,7 @@ class SiftPlan(object):
                            ori_sigma=numpy.float32(par.OriSigma),
                            border_dist=int(par.BorderDist),
                            octave_max=self._octave_limit,
-                           pix_per_kp=int(self.PIX_PER_KP), reserved=0)
+                           pix_per_kp=int(self.PIX_PER_KP), double_im_size=int(dbl))
 
     def __del__(self):
         h = getattr(self, "_handle", None)

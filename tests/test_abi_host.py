@@ -52,7 +52,7 @@ def test_no_gpu_fails_loudly(L):
     from sift_pyocl_amd import _lib
     h = C.c_void_p()
     par = _lib.Params(init_sigma=1.6, peak_thresh=3.4, edge_thresh0=0.08, edge_thresh=0.06, ori_sigma=1.5,
-                      border_dist=5, octave_max=0, pix_per_kp=10, reserved=0)
+                      border_dist=5, octave_max=0, pix_per_kp=10, double_im_size=0)
     assert L.siftmi_plan_create(64, 64, 0, 0, C.byref(par), 0, C.byref(h)) == _lib.EDEVICE
     assert b"device" in L.siftmi_last_error().lower()
     out = np.empty((4, 4), np.float32)

@@ -174,3 +174,50 @@ def test_small_frame_kernels_agree(siftlib, oracle, shape):
         for name, value in opts.items():
             other.set_option(name, value)
         assert_same_keypoints(other.keypoints(img), base, "%r with %r" % (shape, opts))
+
+
+def test_double_im_size(siftlib, oracle):
+    """par.DoubleImSize: the reference only counts the input as blurred by sigma 1.0 instead of 0.5 (plan.py:254, 297, 534:
+    the initial blur becomes sqrt(1.6^2 - 1) wide, 11 taps; nothing is resampled).  Read by the constructor (the taps it
+    prepares) and again at call time (the sigma it looks up): a value changed in between is the reference's KeyError."""
+    import math
+    import sift_pyocl_amd as sp
+    from sift_pyocl_amd.param import par
+    saved = dict(par)
+    img = smooth_noise((333, 402), seed=17, sigma=2.0)
+    img16 = (img / img.max() * 65535).astype(np.uint16)
+    try:
+        plain = sp.SiftPlan(template=img).keypoints(img)
+        par["DoubleImSize"] = 1
+        plan = sp.SiftPlan(template=img)
+        s0, n0 = plan.gaussian_sizes()[0]
+        assert n0 == 11 and abs(s0 - math.sqrt(1.6 ** 2 - 1.0)) < 1e-12
+        want = oracle.keypoints(img, par=oracle.default_params(double_im_size=1))
+        got = plan.keypoints(img)
+        assert_same_keypoints(got, want, "DoubleImSize = 1")
+        assert len(got) != len(plain)                        # the parameter really changed the result
+        assert_same_keypoints(plan.keypoints(img), want, "DoubleImSize = 1, second call")
+        # a typed frame (no fused form of an 11-tap initial blur: the convert pass) and the batched path
+        want16 = oracle.keypoints(img16.astype(np.float32), par=oracle.default_params(double_im_size=1))
+        assert_same_keypoints(sp.SiftPlan(template=img16).keypoints(img16), want16, "DoubleImSize = 1, uint16")
+        bp = sp.BatchPlan(template=img, lanes=2)
+        for r in bp.keypoints_batch([img, img, img]):
+            assert_same_keypoints(r, want, "DoubleImSize = 1, BatchPlan")
+        # init_sigma <= 1.0: no initial blur at all with the parameter set (plan.py:535)
+        flat = sp.SiftPlan(template=img, init_sigma=0.9)
+        assert len(flat.gaussian_sizes()) == 5
+        assert_same_keypoints(flat.keypoints(img), oracle.keypoints(img, par=oracle.default_params(init_sigma=0.9, double_im_size=1)),
+                              "DoubleImSize = 1, init_sigma 0.9")
+        # changed after the constructor: the reference finds no taps for the sigma it now computes (plan.py:585)
+        par["DoubleImSize"] = 0
+        with pytest.raises(KeyError):
+            plan.keypoints(img)
+        with pytest.raises(KeyError):
+            bp.keypoints_batch([img])
+        # ... unless no initial blur is needed either way
+        assert_same_keypoints(sp.SiftPlan(template=img, init_sigma=0.4).keypoints(img),
+                              oracle.keypoints(img, par=oracle.default_params(init_sigma=0.4)), "init_sigma 0.4")
+        par["DoubleImSize"] = 1
+        assert_same_keypoints(plan.keypoints(img), want, "DoubleImSize back to 1")
+    finally:
+        par.update(saved)

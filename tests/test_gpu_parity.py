@@ -23,7 +23,7 @@ def _params(**kw):
     from sift_pyocl_amd import _lib
     d = dict(init_sigma=1.6, peak_thresh=np.float32(255.0 * 0.04 / 3.0), edge_thresh0=np.float32(0.08),
              edge_thresh=np.float32(0.06), ori_sigma=np.float32(1.5), border_dist=5, octave_max=0, pix_per_kp=10,
-             reserved=0)
+             double_im_size=0)
     d.update(kw)
     return _lib.Params(**d)
 

@@ -53,6 +53,26 @@ def test_glibc_build_tolerance(oracle, ref, name):
     print(compare_keypoints_libm(oracle.keypoints(img), ref.keypoints(img), name))
 
 
+def test_double_im_size_identical(oracle, ref):
+    """par.DoubleImSize = 1 (the input counts as blurred by sigma 1.0, plan.py:534: an 11-tap initial blur instead of the
+    15-tap one): the oracle's flag against the reference's own kernels driven with the parameter set, libm isolated."""
+    img = smooth_noise((200, 333), seed=21, sigma=2.5)
+    ref.use("siftmath")
+    saved = ref.PAR["DoubleImSize"]
+    try:
+        if not ref.available():
+            pytest.skip("oracle/_ref/libsiftclref_sm.so not built (needs /root/reference)")
+        ref.PAR["DoubleImSize"] = 1
+        assert abs(ref.sigma_schedule()[0] - (1.6 ** 2 - 1.0) ** 0.5) < 1e-12
+        got = ref.keypoints(img)
+    finally:
+        ref.PAR["DoubleImSize"] = saved
+        ref.use("glibc")
+    want = oracle.keypoints(img, par=oracle.default_params(double_im_size=1))
+    assert_same_keypoints(want, got, "DoubleImSize = 1")
+    assert len(want) != len(oracle.keypoints(img))
+
+
 def test_converters_identical(ref):
     """The typed-frame GPU tests compare against `as_f32` (numpy casts, tests/test_gpu_typed_input.py); pin that
     restatement to the reference's converter kernels (preprocess.cl:53-223), values chosen so that (float)x rounds."""

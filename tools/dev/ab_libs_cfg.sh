@@ -5,9 +5,9 @@ tags=(); while [ "$1" != "--" ] && [ -n "$1" ]; do tags+=("$1"); shift; done; sh
 cp sift_pyocl_amd/libsiftmi.so /tmp/libsiftmi_keep.so
 for cfg in "$@"; do
   echo "== $cfg"
-  for rep in 1 2; do for tag in "${tags[@]}"; do
+  for rep in $(seq 1 ${REPS:-2}); do for tag in "${tags[@]}"; do
     cp sift_pyocl_amd/libsiftmi_$tag.so sift_pyocl_amd/libsiftmi.so
-    echo "   $tag: $(python tools/dev/ab_opts.py base=1 rounds=6 $cfg 2>&1 | grep median)"
+    echo "   $tag: $(python tools/dev/ab_opts.py base=1 rounds=${ROUNDS:-6} $cfg 2>&1 | grep median)"
   done; done
 done
 cp /tmp/libsiftmi_keep.so sift_pyocl_amd/libsiftmi.so

@@ -6,14 +6,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import sift_pyocl_amd as sp
 from util import smooth_noise
-sets = [a for a in sys.argv[1:] if not a.startswith(("size=", "octaves=", "kind=", "rounds="))]
-kw = dict(a.split("=") for a in sys.argv[1:] if a.startswith(("size=", "octaves=", "kind=", "rounds=")))
+sets = [a for a in sys.argv[1:] if not a.startswith(("size=", "octaves=", "kind=", "rounds=", "profile="))]
+kw = dict(a.split("=") for a in sys.argv[1:] if a.startswith(("size=", "octaves=", "kind=", "rounds=", "profile=")))
 size = int(kw.get("size", 4096)); octaves = int(kw.get("octaves", 3)); rounds = int(kw.get("rounds", 15))
 img = smooth_noise((size, size)) if kw.get("kind") == "smooth" else np.random.default_rng(0).random((size, size), dtype=np.float32)
 t = torch.from_numpy(img).cuda()
 plans = []
 for s in sets:
-    plan = sp.SiftPlan(shape=img.shape, dtype=np.float32, octave_max=octaves or None)
+    plan = sp.SiftPlan(shape=img.shape, dtype=np.float32, octave_max=octaves or None, **({"profile": kw["profile"]} if "profile" in kw else {}))
     for kv in s.split(","):
         if "=" in kv and kv != "base=1":
             name, v = kv.split("="); plan.set_option(name, int(v))

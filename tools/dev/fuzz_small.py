@@ -1,6 +1,7 @@
 """dev: randomized HIP-vs-oracle parity over small odd shapes (tile blur, tail kernel with odd pitches, team forms of the
 orientation / descriptor launches, fused hand-off and refinement): python tools/dev/fuzz_small.py [seed] [cases]
-(the CPU oracle is what takes the time: ~20 s per case on the GPU box; seed 1: 63 cases bit-identical, two calls each)"""
+(the CPU oracle is what takes the time: ~20 s per case on the GPU box; seed 1: 63 cases, seed 7: 70 cases (profiles/r05/fuzz_seed7.txt), all
+bit-identical, two calls each)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -267,7 +267,39 @@ def leg_c4(sp, torch, local_rank, steps=3, keep=None):
                         % (C4_FRAMES, C4_SIZE, C4_SIZE, lanes)}
 
 
-def extras(sp, torch, size, n_oct, local_rank, keep=None):
+def leg_pipelined(sp, torch, size, n_oct, local_rank, keep=None):
+    """The 2-lane BatchPlan leg; the LAST leg before the headline's warm-up at every N (the same kernels on the same frame
+    size: the timed region starts from a GPU at its sustained clocks, N = 1 and N > 1 alike)."""
+    out = {}
+    # the pipelined path (BatchPlan, SURVEY 8f-4): what a caller with a stack of frames gets from one GPU (last: the same
+    #     kernels on the same frame size as the headline, whose warm-up follows directly)
+    try:
+        frames = [torch.from_numpy(make_image(i, size)).cuda() for i in range(8)] * 2
+        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct, lanes=2)
+        for _ in range(2):
+            bp.keypoints_batch(frames)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            res = bp.keypoints_batch(frames)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+        tb = sorted(times)[len(times) // 2]
+        out["pipelined"] = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s",
+                            "ms_per_frame": round(1e3 * tb / len(frames), 4), "frames_per_call": len(frames), "lanes": 2,
+                            "keypoints": int(sum(len(r) for r in res)),
+                            "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans; every frame bit-identical "
+                                    "to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
+        if keep is not None:
+            keep.append((bp, frames, res))      # freed by the caller after its timed region (freeing plans idles the GPU)
+        del bp, frames
+    except Exception as exc:
+        out["pipelined"] = {"error": str(exc)[:200]}
+    return out["pipelined"]
+
+
+def extras(sp, torch, size, n_oct, local_rank):
     """Measurements beside the headline, N = 1 only, outside the timed region and never part of `value`."""
     out = {}
     # (2) host-to-host: the reference API takes host numpy arrays (plan.py:450-456); PCIe-inclusive, never `value`
@@ -372,31 +404,6 @@ def extras(sp, torch, size, n_oct, local_rank, keep=None):
         out["c4_one_gpu"] = leg_c4(sp, torch, local_rank)
     except Exception as exc:
         out["c4_one_gpu"] = {"error": str(exc)[:200]}
-    # (4) the pipelined path (BatchPlan): what a caller with a stack of frames gets from one GPU (last: the same
-    #     kernels on the same frame size as the headline, whose warm-up follows directly)
-    try:
-        frames = [torch.from_numpy(make_image(i, size)).cuda() for i in range(8)] * 2
-        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=n_oct, lanes=2)
-        for _ in range(2):
-            bp.keypoints_batch(frames)
-        torch.cuda.synchronize()
-        times = []
-        for _ in range(5):
-            t1 = time.perf_counter()
-            res = bp.keypoints_batch(frames)
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t1)
-        tb = sorted(times)[len(times) // 2]
-        out["pipelined"] = {"value": round(len(frames) * size * size / 1e6 / tb, 2), "unit": "Mpix/s",
-                            "ms_per_frame": round(1e3 * tb / len(frames), 4), "frames_per_call": len(frames), "lanes": 2,
-                            "keypoints": int(sum(len(r) for r in res)),
-                            "note": "BatchPlan.keypoints_batch: frames pipelined over 2 plans; every frame bit-identical "
-                                    "to SiftPlan.keypoints (tests/test_gpu_batch.py)"}
-        if keep is not None:
-            keep.append((bp, frames, res))      # freed by the caller after its timed region (freeing plans idles the GPU)
-        del bp, frames
-    except Exception as exc:
-        out["pipelined"] = {"error": str(exc)[:200]}
     return out
 
 
@@ -538,9 +545,13 @@ def main():
         # (tools/dev/ramp.py: after 0.2 ... 2 s of idle the first ~25 calls run 0.92, 0.85, 0.83, 0.81, 0.80 ms in groups of
         # five before the 0.79 of the steady state; rounds 1-4 ran the legs after the timed region and their lines carry that
         # ramp: compare `steady` across rounds, not `ms_per_step`).  Nothing of the timed region changes.
-        if world == 1 and not args.no_extras:
-            extra = extras(sp, torch, size, n_oct, local_rank, keep=keepalive)
-            order = "legs beside the headline first, then W warm-up + K timed steps, then `steady`, then the CPU baselines"
+        if not args.no_extras:
+            if world == 1:
+                extra = extras(sp, torch, size, n_oct, local_rank)
+            # every rank, at every N: the 2-lane BatchPlan leg directly in front of the warm-up (reported by rank 0)
+            extra["pipelined"] = leg_pipelined(sp, torch, size, n_oct, local_rank, keep=keepalive)
+            order = ("legs beside the headline first (N > 1: the pipelined leg only, on every rank), then W warm-up + K timed "
+                     "steps, then `steady` (N = 1), then the CPU baselines (N = 1)")
         else:
             order = "W warm-up + K timed steps first"
         last = None
@@ -582,8 +593,8 @@ def main():
             print("step ms:", " ".join("%.3f" % (1e3 * (b - a)) for a, b in zip([t0] + marks[:-1], marks)), file=sys.stderr)
         tot_ms = t["total_ms"]; b0_ms = t["blur0_ms"]; b0_px = t["blur0_pixels"]; b0_launches = t["blur0_launches"]
         total_kp = n_kp
-        # beside `value`: the same step over a window long enough for the clocks to settle (the first dozen calls after an
-        # idle period run 3-5 % slower; the driver's 20-step window is mostly that ramp) -- reported, never `value`
+        # beside `value`: the same step over a longer window -- reported, never `value` (rounds 1-4, whose timed region
+        # started from an idle GPU, printed 3-5 % more in `ms_per_step` than here: this is the figure to compare across rounds)
         steady = None
         if world == 1 and not args.no_steady:
             ns = 200

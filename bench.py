@@ -194,6 +194,28 @@ def roofline_valu(ms_per_step):
                       "sources %s = the loaded one" % (rel, library_fingerprint())}
 
 
+def replayed_traffic(rel):
+    """(bytes per launch, where from) of a committed rocprofv3 PMC summary (tools/summarize_prof.py) -- replayed only while it was
+    taken from a library of the same sources as the loaded one and covers all six full-resolution launches of every image."""
+    tfile = os.path.join(ROOT, rel)
+    if not os.path.exists(tfile):
+        return None, None
+    try:
+        tj = json.load(open(tfile))
+        if tj.get("library_fingerprint") != library_fingerprint():
+            return None, ("%s was taken from a library with other sources (fingerprint %s, loaded %s): not replayed"
+                          % (rel, tj.get("library_fingerprint"), library_fingerprint()))
+        if tj.get("complete") and tj["launches_fetch_pass"] == 6 * tj["images_fetch_pass"] \
+                and tj["launches_write_pass"] == 6 * tj["images_write_pass"]:
+            return round(tj["traffic_bytes_per_launch"], 1), (
+                "replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %d + %d launches = 6 per image, "
+                "library fingerprint %s = the loaded one; not observed in this run)"
+                % (rel, tj["launches_fetch_pass"], tj["launches_write_pass"], library_fingerprint()))
+    except Exception:
+        pass
+    return None, None
+
+
 def leg_c3(sp, torch, local_rank, size=16384, steps=3):
     """C3: one 16384^2 frame, all octaves, resident in HBM; its own blur and whole-call rooflines (N = 1 extras leg)."""
     plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, device=local_rank, profile="light")
@@ -214,12 +236,13 @@ def leg_c3(sp, torch, local_rank, size=16384, steps=3):
     balg = bytes_alg(size, size, n_oct, nk / steps)
     del plan, t
     torch.cuda.empty_cache()
+    c3_traffic, c3_src = replayed_traffic(PROFILE_DIR + "/blur_traffic_c3.json") if size == 16384 else (None, None)
     return {"ms_per_image": round(1e3 * el, 3), "value": round(size * size / 1e6 / el, 1), "unit": "Mpix/s", "steps": steps,
             "octaves": n_oct, "keypoints": int(nk / steps), "keypoints_per_s": round(nk / steps / el, 1),
             "roofline": {"bound": "hbm", "kernel": "blur_team_kernel: the 6 full-resolution launches per image (1 GiB planes)",
                          "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
                          "avg_launch_us": round(1e3 * tot["blur0_ms"] / max(tot["blur0_launches"], 1), 1),
-                         "alg_bytes_per_launch": 8.0 * size * size, "traffic": None},
+                         "alg_bytes_per_launch": 8.0 * size * size, "traffic": c3_traffic, "traffic_source": c3_src},
             "roofline_pipeline": {"bound": "hbm", "achieved": round(balg / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(balg / el / 1e9 / HBM_PEAK_GBS, 4), "bytes_alg_per_image": balg},
             "workload": "SiftPlan %dx%d fp32 uniform white noise, all %d octaves x 3 scales, input resident in HBM, records returned to host"
@@ -643,24 +666,9 @@ def main():
             # HBM traffic per full-resolution blur launch: not observable from inside this process -- replayed from the
             # committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, tools/summarize_prof.py)
             # -- and only while the summary was taken from a library of the same sources as the loaded one (its fingerprint)
-            traffic, traffic_src = None, None
-            rel = PROFILE_DIR + "/blur_traffic.json"
-            tfile = os.path.join(ROOT, rel)
-            if os.path.exists(tfile) and size == SIZE and result["n_oct"] == OCTAVES:
-                try:
-                    tj = json.load(open(tfile))
-                    # only a summary that covers all six full-resolution launches of every image of its run counts
-                    if tj.get("library_fingerprint") != library_fingerprint():
-                        traffic_src = ("%s was taken from a library with other sources (fingerprint %s, loaded %s): not replayed"
-                                       % (rel, tj.get("library_fingerprint"), library_fingerprint()))
-                    elif tj.get("complete") and tj["launches_fetch_pass"] == 6 * tj["images_fetch_pass"] \
-                            and tj["launches_write_pass"] == 6 * tj["images_write_pass"]:
-                        traffic = round(tj["traffic_bytes_per_launch"], 1)
-                        traffic_src = ("replayed from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %d + %d "
-                                       "launches = 6 per image, library fingerprint %s = the loaded one; not observed in this run)"
-                                       % (rel, tj["launches_fetch_pass"], tj["launches_write_pass"], library_fingerprint()))
-                except Exception:
-                    traffic = None
+            traffic, traffic_src = (None, None)
+            if size == SIZE and result["n_oct"] == OCTAVES:
+                traffic, traffic_src = replayed_traffic(PROFILE_DIR + "/blur_traffic.json")
             # whole call: algorithmic bytes of an image over the wall time of a step (the light profile brackets only the blur
             # launches: every further event record between kernels would be a bubble in the timed region)
             pipe_ms = kt["tot_ms"] if kt["tot_ms"] > 0 else 1e3 * elapsed

@@ -27,6 +27,10 @@ python tools/bench_align.py > $OUT/bench_align.json 2>> $OUT/bench.err
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt_c3 -o kt --output-format csv -- python $R/bench.py --size 16384 --octaves 0 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-steady > $OUT/bench_c3_16384.json 2>> $OUT/bench.err )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/kt_c4 -o kt --output-format csv -- python $R/bench.py --config c4 --steps 3 --warmup 1 > $OUT/bench_c4.json 2>> $OUT/bench.err )
 for leg in c3 c4; do f=$(ls $OUT/kt_$leg/*/*kernel_stats.csv $OUT/kt_$leg/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/rocprofv3_kernel_stats_$leg.csv; rm -rf $OUT/kt_$leg; done
+# HBM traffic of the 16384^2 blur launches (bench.py's c3 leg replays it)
+bash tools/collect_c3_traffic.sh $TAG > $OUT/collect_c3.log 2>&1
+cp gpurun_out/prof_c3_$TAG/blur_traffic.json $OUT/blur_traffic_c3.json 2>/dev/null
+cp gpurun_out/prof_c3_$TAG/summary.txt $OUT/rocprofv3_summary_c3.txt 2>/dev/null
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls -la $OUT
 # keep what travels back small (gpurun merges at most 64 MiB): the raw CSVs stay on the box

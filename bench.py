@@ -220,7 +220,7 @@ def leg_c3(sp, torch, local_rank, size=16384, steps=3):
     """C3: one 16384^2 frame, all octaves, resident in HBM; its own blur and whole-call rooflines (N = 1 extras leg)."""
     plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, device=local_rank, profile="light")
     t = torch.from_numpy(make_image(0, size)).cuda()
-    for _ in range(2):
+    for _ in range(5):       # (the frame took seconds to generate: ~25 ms of work bring the GPU's clocks back, tools/dev/ramp.py)
         kp = plan.keypoints(t)
     plan.profile_totals(reset=True)
     torch.cuda.synchronize()

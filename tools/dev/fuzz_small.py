@@ -11,9 +11,11 @@ from oracle import pyoracle
 from util import assert_same_keypoints, smooth_noise, white_noise
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+# optional: height range, width range (default: small odd shapes; "1000 2300 1024 2600" reaches the marching blur with odd pitches)
+hlo, hhi, wlo, whi = (int(a) for a in sys.argv[3:7]) if len(sys.argv) > 6 else (40, 700, 40, 900)
 t0 = time.time()
 for it in range(n):
-    H = int(rng.integers(40, 700)); W = int(rng.integers(40, 900))
+    H = int(rng.integers(hlo, hhi)); W = int(rng.integers(wlo, whi))
     kind = it % 3
     img = white_noise((H, W), seed=it) if kind == 0 else smooth_noise((H, W), seed=it, sigma=1.0 + (it % 4))
     dt = [np.float32, np.uint8, np.uint16, np.float32][it % 4]

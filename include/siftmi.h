@@ -95,13 +95,15 @@ int siftmi_plan_capacity(const siftmi_plan *plan, int64_t *records, int64_t *gro
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
- *   launch shapes      "march", "march_wgs", "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
+ *   launch shapes      "march", "march_wgs", "xcd_map" (marching blur, extrema: every XCD takes a contiguous range of tiles; default 1), "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
  *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks", "desc_early_blocks",
  *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_stream", "maps_blocks"
  *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",
  *                      "maps" (0 never / 1 always / 2 by the previous image's count), "maps_density"
  *   stream schedule    "overlap" (0: one stream), "fork" (the octaves below octave 0 as two chains and groups -- octave 1 | the rest: 0 never, 1 always, 2 from five octaves),
- *                      "early_chain" (that chain starts at plane 3 of octave 0: 0 never, 1 always, 2 unless the previous image was keypoint-rich), "spin"
+ *                      "early_chain" (that chain starts at plane 3 of octave 0: 0 never, 1 always, 2 unless the previous image was keypoint-rich),
+ *                      "split" (frames whose later octaves form ONE chain: the octaves below octave 1 built and searched on a stream of their own, one
+ *                      orientation / descriptor launch for the group; default 0), "spin"
  *   diagnostics        "host_timing", "tail_fault" (treat the next n tail launches as timed out: exercises the re-run path) */
 int siftmi_plan_set_option(siftmi_plan *plan, const char *name, int64_t value);
 /* out_is_device of siftmi_plan_keypoints: where the result array lives.  SIFTMI_OUT_PINNED = pinned host memory from

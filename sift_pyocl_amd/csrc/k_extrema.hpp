@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "siftmath.hpp"
+#include "k_xcd.hpp"
 #include <type_traits>
 
 namespace siftk {
@@ -235,7 +236,8 @@ template <bool REFINE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REFINE ? 4 : SIFT_EXT_WAVES, 8))) void extrema_kernel(BlurPlanes b, int W, int H, int border, int rows, double contrast,
                                                       float edth, float4 *__restrict__ cand,
                                                       int *__restrict__ counter, int capacity, RefineArgs ra,
-                                                      int y_lo, int y_hi) {      // rows [y_lo, y_hi) of the detection area (a band), or -1: all of it
+                                                      int y_lo, int y_hi,        // rows [y_lo, y_hi) of the detection area (a band), or -1: all of it
+                                                      int xcd_map) {             // strips in an order that gives every XCD one contiguous range (k_pyramid.hpp)
     __shared__ ExtWaveLds lds_all[4];
     __shared__ int s_pending[4], s_base;
     const int lane = threadIdx.x & 63;
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(REFINE ? 4 
     if (y_lo < 0) { y_lo = border; y_hi = H - border; }
     const int nx = (W - 2 * border + 61) / 62;
     const int ny = (y_hi - y_lo + rows - 1) / rows;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wg = xcd_map ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int wid = wg * 4 + (threadIdx.x >> 6);
     const bool active = wid < nx * ny;                   // no early exit: the workgroup meets at the end
     int pending = 0;                                     // candidates parked in L.buf (wave uniform)
     extrema_strip<SIFT_EXT_BUF, REFINE>(b, W, H, border, rows, active, active ? wid % nx : 0, active ? wid / nx : 0, contrast, edth, cand,

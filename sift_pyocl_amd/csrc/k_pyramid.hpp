@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
+#include "k_xcd.hpp"
 
 namespace siftk {
 
@@ -395,7 +396,8 @@ template <int N, bool NORM, int S, int DT = 0, int HW = 2>
 __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__restrict__ in, float *__restrict__ out,
                                                           int W, int H, int nblocks, int last_subs, int rows_out,
                                                           TapsArg<N> taps, const uint32_t *__restrict__ mm,
-                                                          float *__restrict__ next0) {   // not null: also out[2y][2x] -> next0 (the next octave's plane 0)
+                                                          float *__restrict__ next0,     // not null: also out[2y][2x] -> next0 (the next octave's plane 0)
+                                                          int xcd_map) {
     constexpr int NT = 128;                       // threads per team
     using G = March2Geom<N, NT, S>;
     using SS = SubSplit<N, S>;
@@ -406,11 +408,23 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
     // HW waves form the H team (threads 0 .. 64*HW-1), the last two waves the V team
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 64 * HW ? 1 : 0;     // wave-uniform (a scalar: the team split below is a scalar branch)
     const int tid = role ? (int)threadIdx.x - 64 * HW : (int)threadIdx.x;
-    const int x0 = blockIdx.x * G::TX;
+    // Workgroup -> (strip, segment).  The dispatcher deals workgroup ids round-robin over the eight XCDs, each with its own L2:
+    // with (strip, segment) = (blockIdx.x, blockIdx.y) horizontally adjacent strips -- which read the same halo columns at the
+    // same time -- sit on different XCDs and every halo line comes out of HBM twice.  xcd_map: XCD c takes a contiguous
+    // range of the strip-fastest order (xcd_contiguous), i.e. whole segment rows -- the neighbours' halo lines are L2 hits
+    // (FETCH_SIZE of a 4096^2 launch: 11 taps 101 -> 82 MB, 27 taps 113 -> 91 MB for a 67 MB plane; what is left are the
+    // warm-up rows, which the segment above reads a whole launch later).
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (xcd_map) {
+        const int gx = (int)gridDim.x;
+        const int M = xcd_contiguous(bx + gx * by, gx * (int)gridDim.y);
+        by = M / gx; bx = M - by * gx;
+    }
+    const int x0 = bx * G::TX;
     // A segment outputs `rows_out` rows; it marches nblocks - 1 full accumulator periods of N rows and `last_subs` (1..S)
     // sub-blocks of the last one: just enough rows to complete its outputs, so that the host can pick the segment height
     // that balances the workgroups over the CUs instead of one quantised to multiples of N rows.
-    const int ys = blockIdx.y * rows_out;
+    const int ys = by * rows_out;
     const int yend = min(ys + rows_out, H);
     float mn = 0.f, range = 1.f;
     if (NORM) { mn = ord2f(mm[0]); range = ord2f(mm[1]) - mn; }

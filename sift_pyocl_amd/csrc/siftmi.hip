@@ -105,6 +105,7 @@ struct Options {
     int overlap = 1;         // detection / description streams beside the pyramid stream (0: one stream)
     int march = 1;           // marching blur for large planes (0: tiled blur everywhere)
     int march_wgs = 0;       // workgroups wanted by the marching blur (0: 1024, 768 for 27 taps)
+    int xcd_map = 1;         // marching blur: whole segment rows per XCD (k_pyramid.hpp: the strips' halo columns become L2 hits)
     int ori_blocks = 4096, ori_pad = 0;      // orientation launch: workgroups (upper bound; the kernel cuts it down by the group's count)
     // descriptor launch: workgroups (keypoints are handed out dynamically, so a workgroup stays until the group is done:
     // 1024 = every wave slot of the chip, which starves the other stream's kernels for the whole launch -- 1024^2 smooth
@@ -132,6 +133,8 @@ struct Options {
                              // 0.205 / 0.249 ms, 1024^2 0.281 / 0.328, 2048^2 0.450 / 0.508, 4096^2 with 9 / 5 / 4 / 3 octaves 0.943 / 0.956,
                              // 0.852 / 0.868, 0.830 / 0.833, 0.821 / 0.789 (three octaves: two sparse groups each pay a launch chain beside
                              // octave 0's descriptors), 16384^2 10.46 / 10.48; smoothed noise 4096^2 4.45 / 4.38, 2048^2 1.45 / 1.49
+    int split = 0;           // (when the chain does not fork) the pyramids and detection of the octaves below octave 1 on `stream2` from octave 1's plane 3
+                             // on, beside octave 1's last blurs and detection, into the SAME group: one orientation / descriptor launch for all later octaves
     int early_chain = 2;     // the later octaves' chain starts when plane 3 of octave 0 exists (behind its third blur: octave 1's plane 0 rides on
                              // that launch), not behind its fifth: 0 never, 1 always, 2 unless the previous image of the plan was keypoint-rich
                              // (one keypoint per `maps_density` pixels of octave 0).  Round 3 measured this slower (0.854 -> 0.894 ms): the later
@@ -221,6 +224,8 @@ struct siftmi_plan {
     bool maps_g0 = false, maps_g1 = false;    // the image being enqueued: MAPS forms for octave 0 / the later octaves (groups 1 and 2)
     // the image being enqueued / waited for
     bool early_cur = false;                   // the later octaves' chain started at plane 3 of octave 0
+    bool split_cur = false;                   // the octaves below octave 1 are built and searched on stream2, octave 1's candidates sit in group 1's buffer (option "split")
+    hipEvent_t ev_det2 = nullptr;             // ... and this is the end of their detection
     bool fork_cur = false;                    // octave 1 is a group of its own (1), the octaves below it group 2; else all later octaves in group 2
     unsigned groups_cur = 0;                  // bit g: group g has launches in this image
     int tail_first_cur = 0;                   // first octave of the tail launch (n_oct: none)
@@ -369,7 +374,7 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
     const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
     dim3 grid((unsigned)gx, (unsigned)gy);
     launch_ev(stop, blur_team_kernel<N, NORM, S, DT>, grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
-              rows_out, ta, mm, half);
+              rows_out, ta, mm, half, opt.xcd_map);
 }
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
@@ -522,6 +527,7 @@ OctaveTable octave_table(const siftmi_plan *p) {
 // Here the lists of a group start at kpsize entries and grow when an image needs more (the image is then run again), up
 // to what that rule can ever admit; `reference_overflow` evaluates the rule itself from the per-scale counts.
 int group_of(const siftmi_plan *p, int oct);
+int cand_group_of(const siftmi_plan *p, int oct);
 int64_t list_limit(const siftmi_plan *p, int what, int g) {      // what: 0 candidates, 1 refined, 2 oriented, 3 records
     const int64_t K = p->kpsize, O = std::max(1, p->n_oct);
     int64_t lim = what == 0 ? 3 * K : (what == 1 ? 3 * K * (g == 2 ? O : 1) : (what == 2 ? K * (g == 2 ? O : 1) : K * O));
@@ -548,7 +554,7 @@ int grow_lists(siftmi_plan *p, const Counters *c, bool *grown = nullptr) {
         int64_t need_cand = p->kpsize, need_kp = p->kpsize, need_out = p->kpsize;
         if (c) {
             need_cand = 0;
-            for (int o = 0; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) if (group_of(p, o) == g) need_cand = std::max<int64_t>(need_cand, c->n_cand[o]);
+            for (int o = 0; o < p->n_oct && o < SIFT_MAX_OCTAVES; o++) if (cand_group_of(p, o) == g) need_cand = std::max<int64_t>(need_cand, c->n_cand[o]);
             need_kp = c->g_kp[g]; need_out = c->g_out[g];
         }
         const int64_t cc = want(G.cap_cand, need_cand, list_limit(p, 0, g)), ck = want(G.cap_kp, need_kp, list_limit(p, 1, g)),
@@ -595,6 +601,9 @@ bool reference_overflow(const siftmi_plan *p, const Counters &c) {
 // Group of an octave in the image being enqueued: octave 0, octave 1, everything below -- or, when the later octaves form
 // one chain (single stream, option "fork" = 0, octave 1 inside the tail launch), octave 0 and everything below it.
 int group_of(const siftmi_plan *p, int oct) { return oct == 0 ? 0 : ((oct == 1 && p->fork_cur) ? 1 : 2); }
+// ... and the group whose CANDIDATE buffer the octave's detection uses (a buffer holds one octave at a time): with option
+// "split" octave 1 is searched beside the octaves below it, so its candidates take group 1's otherwise unused buffer.
+int cand_group_of(const siftmi_plan *p, int oct) { return (oct == 1 && p->split_cur) ? 1 : group_of(p, oct); }
 
 // Extrema of the three detection scales + sub-pixel refinement of one octave; survivors are appended to the refined list
 // of the octave's group (tagged with the octave).
@@ -608,7 +617,8 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
     BlurPlanes bp;
     for (int s = 0; s < 6; s++) bp.p[s] = p->plane(oct, s);
     const int border = p->par.border_dist;
-    const int ccap = (int)G.cap_cand, kcap = (int)G.cap_kp;
+    GroupLists &GC = p->grp[cand_group_of(p, oct)];
+    const int ccap = (int)GC.cap_cand, kcap = (int)G.cap_kp;
     int *n_cand = &p->cnt->n_cand[oct];
     if (!(W > 2 * border && H > 2 * border)) return;
     const int rows = p->opt.ext_rows > 0 ? p->opt.ext_rows : extrema_strip_rows(W, H, border, p->opt.ext_strips);
@@ -624,19 +634,19 @@ void launch_detect_octave(siftmi_plan *p, int oct, hipStream_t st) {
         snprintf(lab, sizeof lab, "local_maxmin+interp_keypoint %d", oct);
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(extrema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                           contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
+                           contrast_threshold(p->par), edth, GC.cand, n_cand, ccap, ra, -1, -1, p->opt.xcd_map);
         return;
     }
     {
         snprintf(lab, sizeof lab, "local_maxmin %d", oct);
         Scope sc(p, lab, false, 0, st);
         hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, bp, W, H, border, rows,
-                           contrast_threshold(p->par), edth, G.cand, n_cand, ccap, ra, -1, -1);
+                           contrast_threshold(p->par), edth, GC.cand, n_cand, ccap, ra, -1, -1, p->opt.xcd_map);
     }
     {
         snprintf(lab, sizeof lab, "interp_keypoint+compact %d", oct);
         Scope sc(p, lab, false, 0, st);
-        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)G.cand,
+        hipLaunchKernelGGL(refine_kernel, dim3(512), dim3(256), 0, st, bp, W, H, (const float4 *)GC.cand,
                            (const int *)n_cand, ccap, p->par.peak_thresh, (float)p->par.init_sigma, G.kp,
                            G.kp_aux, &p->cnt->g_kp[g], kcap, oct, &p->cnt->c_scale[oct][0]);
     }
@@ -908,6 +918,7 @@ int siftmi_plan_destroy(siftmi_plan *p) {
     if (p->stream2) { hipStreamSynchronize(p->stream2); hipStreamDestroy(p->stream2); }
     if (p->stream3) { hipStreamSynchronize(p->stream3); hipStreamDestroy(p->stream3); }
     if (p->ev_p3) hipEventDestroy(p->ev_p3);
+    if (p->ev_det2) hipEventDestroy(p->ev_det2);
     if (p->ev_early) hipEventDestroy(p->ev_early);
     if (p->ev_maps0) hipEventDestroy(p->ev_maps0);
     for (hipEvent_t e : p->ev_pyr) hipEventDestroy(e);
@@ -969,6 +980,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "overlap") { o.overlap = v != 0; p->overlap = o.overlap; }
     else if (n == "march") o.march = v != 0;
     else if (n == "march_wgs") o.march_wgs = v > 0 ? v : 0;
+    else if (n == "xcd_map") o.xcd_map = v != 0;
     else if (n == "ori_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_blocks must be >= 1"); o.ori_blocks = v; }
     else if (n == "ori_pad") o.ori_pad = v > 0 ? v : 0;
     else if (n == "desc_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_blocks must be >= 1"); o.desc_blocks = v; }
@@ -991,6 +1003,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "maps_density") { if (v < 1) return fail(SIFTMI_EINVAL, "maps_density must be >= 1"); o.maps_density = v; }
     else if (n == "early_chain") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "early_chain must be 0 (never), 1 (always) or 2 (unless the previous image was keypoint-rich)"); o.early_chain = v; }
     else if (n == "desc_early_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_early_blocks must be >= 1"); o.desc_early_blocks = v; }
+    else if (n == "split") o.split = v != 0;
     else if (n == "fork") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "fork must be 0 (never), 1 (always) or 2 (frames of five octaves and more)"); o.fork = v; }
     else if (n == "desc_small_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_small_blocks must be >= 1"); o.desc_small_blocks = v; }
     else if (n == "desc_dense_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_dense_blocks must be >= 1"); o.desc_dense_blocks = v; }
@@ -1166,8 +1179,13 @@ int enqueue_body(siftmi_plan *p) {
     // the later octaves in two chains: two streams, an octave 1 outside the tail launch, at least one octave below it
     const bool fork = two && (p->opt.fork == 1 || (p->opt.fork == 2 && p->n_oct >= 5)) && p->n_oct > 2 && tail_first != 1 && p->grp[1].okp;
     p->fork_cur = fork;
+    // ... or ONE group whose octaves are built and searched on two streams (option "split"; not beside octave 0's gradient maps,
+    // which use stream2)
+    const bool split = two && !fork && p->opt.split && p->n_oct > 2 && tail_first != 1 && p->grp[1].cand && !p->maps_g0;
+    p->split_cur = split;
+    if (split && !p->ev_det2) HIPCHK(hipEventCreateWithFlags(&p->ev_det2, SIFT_SYNC_EVENT));
     hipStream_t later = two ? p->stream3 : p->stream;       // octave 1's chain (every later octave's without the fork)
-    hipStream_t below = fork ? p->stream2 : later;          // the chain of the octaves below octave 1
+    hipStream_t below = (fork || split) ? p->stream2 : later;   // the chain of the octaves below octave 1
     // ... starts at plane 3 of octave 0 (option "early_chain"): needs the fused hand-off (octave 1's plane 0 written by octave 0's third blur)
     bool early = two && p->opt.early_chain && p->n_oct > 1 && p->profile <= 1 && p->opt.fused_shrink && tail_first != 1;
     if (early && p->opt.early_chain == 2) {
@@ -1208,7 +1226,7 @@ int enqueue_body(siftmi_plan *p) {
             if (s == 2 && oct == 0 && early) {
                 if (!p->ev_early) HIPCHK(hipEventCreateWithFlags(&p->ev_early, SIFT_SYNC_EVENT));
                 done = p->ev_early;
-            } else if (s == 2 && oct == 1 && fork) {
+            } else if (s == 2 && oct == 1 && (fork || split)) {
                 done = p->ev_p3;       // plane 3 of octave 1 and plane 0 of octave 2 exist (or will be shrunk from it): the chain below starts here
             } else if (s == 4 && oct == 0 && p->profile == 1 && p->chain) {
                 Scope *ch = static_cast<Scope *>(p->chain);
@@ -1220,7 +1238,7 @@ int enqueue_body(siftmi_plan *p) {
                 Scope sc(p, lab, true, (double)W * H, pyr, p->profile > 1 ? oct : -2);      // (light profile: octave 0 is inside the open bracket, the others are not timed)
                 if (launch_blur(p, p->plane(oct, s), p->plane(oct, s + 1), W, H, p->taps[s], false, pyr, s == 2 ? half : nullptr, done)) handed[oct + 1] = true;
             }
-            if (s == 2 && oct == 1 && fork) HIPCHK(hipStreamWaitEvent(below, p->ev_p3, 0));
+            if (s == 2 && oct == 1 && (fork || split)) HIPCHK(hipStreamWaitEvent(below, p->ev_p3, 0));
         }
         if (oct == 0 && p->profile == 1) {
             Scope *ch = static_cast<Scope *>(p->chain);
@@ -1266,8 +1284,14 @@ int enqueue_body(siftmi_plan *p) {
                 if ((rc = launch_describe_group(p, 1, later, slot++))) return rc;
             }
         }
-        if (p->maps_g1) launch_gradient_maps(p, fork ? 2 : 1, p->n_oct, below);
-        if ((rc = launch_describe_group(p, 2, below, slot++))) return rc;
+        hipStream_t desc2 = below;
+        if (split) {              // the two detection chains meet: orientation and description of the group follow octave 1's chain
+            HIPCHK(hipEventRecord(p->ev_det2, below));
+            HIPCHK(hipStreamWaitEvent(later, p->ev_det2, 0));
+            desc2 = later;
+        }
+        if (p->maps_g1) launch_gradient_maps(p, fork ? 2 : 1, p->n_oct, desc2);
+        if ((rc = launch_describe_group(p, 2, desc2, slot++))) return rc;
     }
     if (p->chain) { delete static_cast<Scope *>(p->chain); p->chain = nullptr; }   // no octave closed the light-profile bracket (n_oct == 0)
     if (slot == 0) {                           // no octave at all: the counters (min / max) still come back
@@ -2355,7 +2379,7 @@ int siftmi_stage_local_maxmin(int32_t dev, const float *blurs, int32_t W, int32_
         const int nx = (W - 2 * border + 61) / 62, ny = (H - 2 * border + rows - 1) / rows;
         const float edth = (octsize <= 1) ? par->edge_thresh0 : par->edge_thresh;
         hipLaunchKernelGGL(extrema_kernel<false>, dim3((unsigned)((nx * ny + 3) / 4)), dim3(256), 0, 0, bp, W, H, border, rows,
-                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity, RefineArgs{}, -1, -1);
+                           contrast_threshold(*par), edth, c.as<float4>(), &cnt.as<Counters>()->n_cand[0], (int)capacity, RefineArgs{}, -1, -1, 1);
     }
     if ((rc = stage_end())) return rc;
     Counters hc;

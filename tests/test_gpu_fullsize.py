@@ -78,7 +78,10 @@ def test_2048_keypoint_rich_bit_exact(siftlib, oracle):
     assert_same_keypoints(got, want, "2048 smoothed noise")
     # launch-layout options that only large frames reach (none may change a byte): the later octaves as one chain and group or
     # as two, one stream -- each with the lazy gradient and with full maps
-    for opts in (dict(fork=0), dict(fork=1), dict(early_chain=0), dict(early_chain=1, fork=1), dict(overlap=0)):
+    # ... the tiles in plain workgroup order (xcd_map = 0), the octaves below octave 1 searched on a stream of their own into
+    # the one group of the later octaves (split; with maps = 1 it does not apply and the plain single chain runs)
+    for opts in (dict(fork=0), dict(fork=1), dict(early_chain=0), dict(early_chain=1, fork=1), dict(overlap=0), dict(xcd_map=0),
+                 dict(split=1, fork=0), dict(split=1, fork=0, early_chain=1)):
         for maps in (0, 1):
             p2 = sp.SiftPlan(template=img)
             p2.set_option("maps", maps)

@@ -169,7 +169,8 @@ def test_small_frame_kernels_agree(siftlib, oracle, shape):
         assert_same_keypoints(base, want, "defaults vs oracle %r" % (shape,))
     for opts in (dict(tail=0), dict(tail=0, ext_rows=32), dict(tail=1, ext_rows=8), dict(tail=1, overlap=0),
                  dict(desc_team=0), dict(desc_team=1 << 30, fork=0), dict(fork=1), dict(early_chain=0), dict(early_chain=1, fork=0),
-                 dict(desc_team=0, desc_dynamic=0, desc_blocks=333), dict(desc_team=0, desc_blocks=7, ori_blocks=77), dict(ori_team=0), dict(ori_team=1 << 30, ori_blocks=5), dict(fused_shrink=0), dict(fused_shrink=1, overlap=0, tail=0), dict(fused_refine=0), dict(fused_refine=2, tail=0)):
+                 dict(desc_team=0, desc_dynamic=0, desc_blocks=333), dict(desc_team=0, desc_blocks=7, ori_blocks=77), dict(ori_team=0), dict(ori_team=1 << 30, ori_blocks=5), dict(fused_shrink=0), dict(fused_shrink=1, overlap=0, tail=0), dict(fused_refine=0), dict(fused_refine=2, tail=0),
+                 dict(xcd_map=0), dict(split=1, fork=0), dict(split=1, fork=0, early_chain=0, tail=0), dict(split=1, fork=0, xcd_map=0, fused_refine=0)):
         other = sp.SiftPlan(template=img)
         for name, value in opts.items():
             other.set_option(name, value)

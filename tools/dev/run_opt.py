@@ -4,10 +4,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import sift_pyocl_amd as sp
-sets = [a for a in sys.argv[1:] if not a.startswith(("size=", "octaves=", "n="))]
-kw = dict(a.split("=") for a in sys.argv[1:] if a.startswith(("size=", "octaves=", "n=")))
+sets = [a for a in sys.argv[1:] if not a.startswith(("size=", "octaves=", "n=", "kind="))]
+kw = dict(a.split("=") for a in sys.argv[1:] if a.startswith(("size=", "octaves=", "n=", "kind=")))
 size = int(kw.get("size", 4096)); octaves = int(kw.get("octaves", 3)); n = int(kw.get("n", 6))
-t = torch.from_numpy(np.random.default_rng(0).random((size, size), dtype=np.float32)).cuda()
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import smooth_noise
+img = smooth_noise((size, size)) if kw.get("kind") == "smooth" else np.random.default_rng(0).random((size, size), dtype=np.float32)
+t = torch.from_numpy(img).cuda()
 plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, octave_max=octaves or None)
 for s in sets:
     for kv in s.split(","):

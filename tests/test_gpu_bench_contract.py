@@ -51,9 +51,17 @@ def test_bench_single_gpu_line():
     assert d["match_100k"]["pairs"] == d["match_100k"]["expected_pairs"]
 
 
+def free_port():
+    """a port nobody listens on right now (a fixed one collides with a lingering worker of an earlier run)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_bench_two_ranks_rehearsal():
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-             "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-gpu"])
+             "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-gpu"])
     check_common(d, 2, 3, 1)
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
     assert abs(d["value"] - 2 * 4096 * 4096 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01

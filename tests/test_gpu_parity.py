@@ -405,6 +405,9 @@ def test_keypoints_octave_limit_and_profile(siftlib, oracle):
     got = plan.keypoints(img)
     exp = oracle.keypoints(img, oracle.default_params(octave_max=3))
     assert_same_keypoints(got, exp, "octave_max=3")
+    # (the stage times of a process's FIRST call hold the lazy load of every kernel's code object -- 80 ms on a fresh box --:
+    # the bound below is about the second call)
+    assert_same_keypoints(plan.keypoints(img), exp, "octave_max=3, second call")
     kt = plan.kernel_times()
     assert kt["total_ms"] > 0 and kt["blur_launches"] == 16 and kt["blur_ms"] <= kt["total_ms"]
     assert plan.minmax() == (float(img.min()), float(img.max()))

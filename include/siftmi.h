@@ -231,6 +231,9 @@ int siftmi_match_destroy(siftmi_matcher *plan);
  * image.cl:119 | image.cl:235 + algebra.cl:57 | image.cl:47 | orientation_cpu.cl:41 |
  * keypoints_cpu.cl:36 | preprocess.cl:267 | preprocess.cl:53-223 */
 int siftmi_stage_gaussian_taps(float sigma, int32_t size, float *out);
+/* (host only, no reference counterpart) position of workgroup `id` of a grid of `n` in the XCD-contiguous order the marching
+ * blur and the extrema pass use (csrc/k_xcd.hpp): the tile it works on.  A bijection of [0, n) for every n. */
+int32_t siftmi_stage_xcd_order(int32_t id, int32_t n);
 int siftmi_stage_minmax_normalize(int32_t device_id, const float *in, float *out, int32_t W, int32_t H,
                                   float *min_out, float *max_out);
 int siftmi_stage_blur(int32_t device_id, const float *in, float *out, int32_t W, int32_t H,

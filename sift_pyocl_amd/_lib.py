@@ -82,6 +82,7 @@ _SIGNATURES = {
     "siftmi_match_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "siftmi_match_destroy": (C.c_int, [C.c_void_p]),
     "siftmi_stage_gaussian_taps": (C.c_int, [C.c_float, C.c_int32, C.c_void_p]),
+    "siftmi_stage_xcd_order": (C.c_int32, [C.c_int32, C.c_int32]),
     "siftmi_stage_minmax_normalize": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "siftmi_stage_blur": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),

@@ -8,9 +8,9 @@ namespace siftk {
 // workgroup ids of a grid round-robin over the eight XCDs (id L runs on XCD L % 8, in ascending order of L / 8), and each
 // XCD has its own L2: neighbours in id share nothing.  M(L) = (start of XCD L % 8's range) + L / 8 is a bijection of
 // [0, n) for every n (the first n % 8 XCDs own one workgroup more), ascending in time on every XCD.
-__device__ __forceinline__ int xcd_contiguous(int L, int n) {
+__host__ __device__ __forceinline__ int xcd_contiguous(int L, int n) {
     const int c = L & 7, q = n >> 3, r = n & 7;
-    return c * q + min(c, r) + (L >> 3);
+    return c * q + (c < r ? c : r) + (L >> 3);
 }
 
 }  // namespace siftk

@@ -2318,6 +2318,8 @@ int siftmi_stage_gaussian_taps(float sigma, int32_t size, float *out) {
     return gaussian_taps(sigma, size, out);
 }
 
+int32_t siftmi_stage_xcd_order(int32_t id, int32_t n) { return (n > 0 && id >= 0 && id < n) ? siftk::xcd_contiguous(id, n) : -1; }
+
 int siftmi_stage_minmax_normalize(int32_t dev, const float *in, float *out, int32_t W, int32_t H, float *mn, float *mx) {
     int rc = stage_begin(dev); if (rc) return rc;
     const size_t N = (size_t)W * H;

@@ -100,6 +100,20 @@ def test_host_gaussian_taps_match_oracle(L, oracle):
     assert L.siftmi_stage_gaussian_taps(C.c_float(1.0), 0, out.ctypes.data) != 0
 
 
+def test_xcd_contiguous_order_is_a_bijection(L):
+    """csrc/k_xcd.hpp: workgroup id -> tile.  Every grid size must map [0, n) onto itself (a tile worked on twice or never would
+    be a wrong plane), XCD c = id % 8 must own one contiguous range, ascending in id."""
+    for n in list(range(1, 70)) + [255, 256, 257, 768, 1020, 1024, 2112, 4097]:
+        order = [L.siftmi_stage_xcd_order(i, n) for i in range(n)]
+        assert sorted(order) == list(range(n)), n
+        for c in range(min(8, n)):
+            mine = order[c::8]
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (n, c)
+        starts = [order[c] for c in range(min(8, n))]
+        assert starts == sorted(starts), n
+    assert L.siftmi_stage_xcd_order(5, 5) == -1 and L.siftmi_stage_xcd_order(-1, 5) == -1 and L.siftmi_stage_xcd_order(0, 0) == -1
+
+
 def test_utils_follow_reference_formulas():
     from sift_pyocl_amd.utils import calc_size, kernel_size, nextpower
     assert [kernel_size(s, True) for s in (1.5198684, 1.2262735, 1.5450078, 1.9465878, 2.452547, 3.0900156)] == [15, 11, 15, 17, 21, 27]

@@ -26,6 +26,10 @@ for it in range(n):
     if it % 4 == 1: plan.set_option("desc_team", 0); plan.set_option("ori_team", 0)
     if it % 4 == 2: plan.set_option("overlap", 0)
     if it % 4 == 3: plan.set_option("fork", 0)
+    # (since the XCD-contiguous order: every eighth case builds the later octaves' pyramids on two streams into one group --
+    # option "split" needs the unforked chain --, every fifth deals the tiles in plain workgroup order)
+    if it % 8 == 7: plan.set_option("split", 1)
+    if it % 5 == 4: plan.set_option("xcd_map", 0)
     got = plan.keypoints(img)
     assert_same_keypoints(got, want, "fuzz %d %dx%d %s" % (it, H, W, np.dtype(dt).name))
     assert_same_keypoints(plan.keypoints(img), want, "fuzz %d second call" % it)

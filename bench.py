@@ -37,7 +37,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-PROFILE_DIR = "profiles/r05"           # the round's rocprofv3 summaries (tools/collect_round.sh); replayed only for the library they describe
+PROFILE_DIR = "profiles/r06"           # the round's rocprofv3 summaries (tools/collect_round.sh); replayed only for the library they describe
 
 
 def library_fingerprint():
@@ -117,6 +117,22 @@ def cpu_reference_kernels(size, octaves):
         return {"error": str(exc)[:200]}
 
 
+def rank_envs(n, port, base=None):
+    """The environment of each of the N ranks `--gpus N` starts on ONE node (what `torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` would set): rank r is pinned to GPU r through LOCAL_RANK (main() calls
+    torch.cuda.set_device(LOCAL_RANK); the plans take the same ordinal), one rendezvous port for all of them, dmabuf IPC
+    for RCCL (HSA_ENABLE_IPC_MODE_LEGACY=0), one OpenMP thread per rank unless the caller set a count."""
+    base = dict(os.environ if base is None else base)
+    envs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")     # as torch.distributed.run does: N ranks must not each spin on every core
+        envs.append(env)
+    return envs
+
+
 def spawn_ranks(args):
     """`--gpus N` without a launcher: start N copies of this script, one per GPU, and wait for them."""
     import torch
@@ -130,11 +146,7 @@ def spawn_ranks(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", "1")     # as torch.distributed.run does: N ranks must not each spin on every core
+    for r, env in enumerate(rank_envs(args.gpus, port)):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -192,6 +204,21 @@ def roofline_valu(ms_per_step):
             "source": "instruction counts replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU* of this command, tools/valu_frame.sh); "
                       "issue intervals from profiles/r04/valu_issue_rate.txt (tools/ubench/valu_rate.hip); fingerprint of the library's "
                       "sources %s = the loaded one" % (rel, library_fingerprint())}
+
+
+def rocprof_launch_us(rel):
+    """Average duration (us) of the full-resolution blur launches in the committed `rocprofv3 --kernel-trace --stats` summary of
+    this command (tools/summarize_prof.py writes it beside the traffic), or None: when the file is missing, predates the
+    field, or describes a library of other sources.  bench.py prints it beside the live hipEvent figure so that the line and
+    profiles/ cannot drift apart unnoticed."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, rel)))
+        if tj.get("library_fingerprint") != library_fingerprint():
+            return None
+        v = tj.get("rocprof_avg_launch_us_full_resolution")
+        return float(v) if v else None
+    except Exception:
+        return None
 
 
 def replayed_traffic(rel):
@@ -501,7 +528,7 @@ def main():
         # ---------------------------------------------------------------- C4: 64 x 2048^2 sharded over the ranks
         mine = shard_indices(C4_FRAMES, rank, world)
         frames = [torch.from_numpy(make_image(1000 + i, size)).cuda() for i in mine]
-        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=octaves or None)
+        bp = sp.BatchPlan(shape=(size, size), dtype=np.float32, device=local_rank, octave_max=octaves or None, profile="light")
         n_oct = bp.octave_max
         torch.cuda.synchronize()
 
@@ -528,6 +555,10 @@ def main():
                     % (C4_FRAMES, size, size, world, len(mine), bp.lanes))
         result.update(scaling="strong", images_per_step=C4_FRAMES, kp_per_img=total_kp / max(K, 1) / C4_FRAMES, n_oct=n_oct)
         kt = None
+        try:
+            c4_blur = bp.blur_times()          # rank 0's lanes, last batch: brackets around each frame's full-resolution blur launches
+        except Exception:
+            c4_blur = None
     else:
         # ---------------------------------------------------------------- C2: one 4096^2 frame per step and GPU
         plan = sp.SiftPlan(shape=(size, size), dtype=np.float32, devicetype="GPU", device=local_rank, profile="light",
@@ -640,7 +671,14 @@ def main():
                       exchange_ms=None if exchange_ms is None else round(exchange_ms, 3), exchange_bytes=exchange_bytes)
         kt = dict(b0_ms=b0_ms, b0_px=b0_px, b0_launches=b0_launches, tot_ms=tot_ms, steady=steady)
 
+    rank_ms = None
     if distributed:
+        # every rank's own time of the region (the reported one is their maximum): a first multi-GPU curve can then be read
+        # without a re-run -- a slow rank, a slow link and a uniform slow-down look different here
+        mine_el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+        all_el = [torch.zeros_like(mine_el) for _ in range(world)]
+        dist.all_gather(all_el, mine_el)
+        rank_ms = [1e3 * float(t.item()) / max(K, 1) for t in all_el]
         el = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -665,6 +703,9 @@ def main():
                        "exchange_ms": result.get("exchange_ms"), "exchange_bytes_per_rank": result.get("exchange_bytes"),
                        "backend": backend if distributed else None, "world_size_observed": world_observed},
         }
+        if rank_ms is not None:
+            out["ms_per_step_ranks"] = {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "per_rank": [round(v, 4) for v in rank_ms],
+                                        "note": "each rank's own wall time of the timed region / K; `ms_per_step` is the maximum"}
         if kt is not None:
             blur_gbs = (8.0 * kt["b0_px"] / 1e9) / (kt["b0_ms"] / 1e3) if kt["b0_ms"] > 0 else 0.0
             # HBM traffic per full-resolution blur launch: not observable from inside this process -- replayed from the
@@ -677,6 +718,8 @@ def main():
             # launches: every further event record between kernels would be a bubble in the timed region)
             pipe_ms = kt["tot_ms"] if kt["tot_ms"] > 0 else 1e3 * elapsed
             pipe_gbs = (bytes_alg(size, size, result["n_oct"], result["kp_per_img"]) * K / 1e9) / (pipe_ms / 1e3) if pipe_ms > 0 else 0.0
+            rp_us = rocprof_launch_us(PROFILE_DIR + "/blur_traffic.json") if (size == SIZE and result["n_oct"] == OCTAVES) else None
+            rp_gbs = (8.0 * size * size / 1e9) / (rp_us / 1e6) if rp_us else None
             out["roofline"] = {
                 "bound": "hbm",
                 "kernel": "blur_team_kernel<N, NORM, S> (fused separable Gaussian blur): the %d full-resolution (octave 0) "
@@ -684,15 +727,37 @@ def main():
                           "overlap another kernel, later octaves run concurrently with the detection streams"
                           % (kt["b0_launches"] // max(K, 1)),
                 "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(blur_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
+                # SURVEY 8(d)'s own definition, with equal standing: algorithmic bytes of a whole call over the time of its kernels
+                "frac_pipeline": round(pipe_gbs / HBM_PEAK_GBS, 4), "achieved_pipeline": round(pipe_gbs, 1),
+                # the dominant kernel's fraction again, from the COMMITTED rocprofv3 kernel stats of this command (null when
+                # that summary describes other sources than the loaded library's)
+                "frac_rocprof": None if rp_gbs is None else round(rp_gbs / HBM_PEAK_GBS, 4),
+                "avg_launch_us_rocprof": None if rp_us is None else round(rp_us, 2),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(1e3 * kt["b0_ms"] / max(kt["b0_launches"], 1), 2),
                 "alg_bytes_per_launch": round(8.0 * kt["b0_px"] / max(kt["b0_launches"], 1), 1),
-                "timing": "one hipEvent pair on the plan's pyramid stream around the 6 back-to-back launches "
-                          "(inter-kernel gaps included)"}
+                "timing": "frac / achieved: one hipEvent pair on the plan's pyramid stream around the 6 back-to-back launches "
+                          "(inter-kernel gaps included), live; frac_pipeline: bytes_alg of an image (roofline_pipeline) over the "
+                          "hipEvent time first -> last kernel of a call, live; frac_rocprof: 8 B/px over the average duration of "
+                          "the same launches in %s/rocprofv3_summary.txt (a traced run of --steps 10 --warmup 2: shorter, on the "
+                          "clock ramp, hence below the live figure)" % PROFILE_DIR}
             out["roofline_pipeline"] = {"bound": "hbm", "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
                                         "ms_per_image": round(pipe_ms / max(K, 1), 4), "time": "hipEvent first -> last kernel" if kt["tot_ms"] > 0 else "wall clock of the timed steps",
                                         "bytes_alg_per_image": bytes_alg(size, size, result["n_oct"], result["kp_per_img"])}
+        if c4:
+            # the batch's rooflines, at every N: the dominant kernel from rank 0's own light-profile brackets (its lanes overlap, so
+            # a bracket also holds other lanes' kernels: a lower bound of the kernel's rate), the whole job from the wall clock
+            balg = C4_FRAMES * bytes_alg(size, size, result["n_oct"], result["kp_per_img"])
+            pipe_gbs = balg * K / 1e9 / elapsed if elapsed > 0 else 0.0
+            blur_gbs = (8.0 * c4_blur["blur0_pixels"] / 1e9) / (c4_blur["blur0_ms"] / 1e3) if c4_blur and c4_blur.get("blur0_ms", 0) > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "the full-resolution (%dx%d) blur launches of rank 0's share of the batch (light-profile "
+                                                         "brackets of its lanes, last step; lanes overlap)" % (size, size),
+                               "achieved": round(blur_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
+                               "frac_pipeline": round(pipe_gbs / HBM_PEAK_GBS / max(world, 1), 4), "achieved_pipeline": round(pipe_gbs, 1),
+                               "traffic": None,
+                               "timing": "frac_pipeline: algorithmic bytes of the whole batch over the wall time of a step, per GPU (divided by N)"}
         if kt is not None and size == SIZE and result["n_oct"] == OCTAVES and world == 1:
             rv = roofline_valu(1e3 * elapsed / max(K, 1))
             if rv is not None:

@@ -224,6 +224,10 @@ int siftmi_match_ex(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, i
                     const siftmi_keypoint *kp2, int64_t n2, int32_t kp2_is_device, float ratio_th, int32_t roi_mode,
                     int32_t mutual, int32_t *pairs, int64_t capacity, int64_t *n_out, int64_t *n_total);
 int siftmi_match_last_kernel_ms(const siftmi_matcher *plan, float *ms);
+/* profile != 0 at creation: device time in ms of the last call's stages, in the order of the events the reference
+ * appends under profile=True (sift-src/match.py:226-263): ms4[0] "copy H->D KP_1", [1] "copy H->D KP_2", [2] "matching",
+ * [3] "copy D->H match"; -1 where the stage did not run (device-resident list, no pair to copy). */
+int siftmi_match_last_stage_ms(const siftmi_matcher *plan, float *ms4);
 int siftmi_match_destroy(siftmi_matcher *plan);
 
 /* ---- per-stage entry points (host pointers in/out; golden-vector replay, one reference kernel each)
@@ -238,6 +242,14 @@ int siftmi_stage_minmax_normalize(int32_t device_id, const float *in, float *out
                                   float *min_out, float *max_out);
 int siftmi_stage_blur(int32_t device_id, const float *in, float *out, int32_t W, int32_t H,
                       const float *taps, int32_t ntaps);
+/* the same stage with a plan's launch choices exposed (test hook for the large-plane kernels): `in` holds a frame of
+ * `in_dtype` (SIFTMI_F32, or an integer / RGB8 code: those enter through the normalising 15-tap blur only, as in a plan);
+ * norm != 0: min/max of the frame first (reductions.cl:62-241), then the blur with `normalizes` (preprocess.cl:239-252)
+ * applied to its inputs; xcd_map: workgroup order of the marching kernel; march_wgs: its workgroup count (0: default);
+ * *kernel_used (may be null): 0 generic two-pass, 1 tiled kernel, 2 marching team kernel. */
+int siftmi_stage_blur_ex(int32_t device_id, const void *in, int32_t in_dtype, float *out, int32_t W, int32_t H,
+                         const float *taps, int32_t ntaps, int32_t norm, int32_t xcd_map, int32_t march_wgs,
+                         int32_t *kernel_used);
 int siftmi_stage_dog(int32_t device_id, const float *blur_a, const float *blur_b, float *out, int64_t n);
 /* blurs: 6 planes (H,W); out: (capacity,4) floats (peak,row,col,scale) for scales 1..3 */
 int siftmi_stage_local_maxmin(int32_t device_id, const float *blurs, int32_t W, int32_t H, int32_t octsize,

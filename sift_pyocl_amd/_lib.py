@@ -80,12 +80,15 @@ _SIGNATURES = {
     "siftmi_match_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "siftmi_match_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "siftmi_match_last_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "siftmi_match_destroy": (C.c_int, [C.c_void_p]),
     "siftmi_stage_gaussian_taps": (C.c_int, [C.c_float, C.c_int32, C.c_void_p]),
     "siftmi_stage_xcd_order": (C.c_int32, [C.c_int32, C.c_int32]),
     "siftmi_stage_minmax_normalize": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "siftmi_stage_blur": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "siftmi_stage_blur_ex": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "siftmi_stage_dog": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "siftmi_stage_local_maxmin": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params),
                                             C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -118,6 +121,8 @@ def source_fingerprint():
                    [os.path.join(os.path.dirname(here), "include", "siftmi.h")])
     h = hashlib.sha256()
     for f in files:
+        if not os.path.exists(f):        # an installed package without the repository's include/: no fingerprint, nothing replayed
+            return None
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

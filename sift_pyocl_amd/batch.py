@@ -322,16 +322,21 @@ def keypoints_batch(images, plan=None, rank=None, world_size=None, gather=True, 
     # and the kind of plan the caller passed (a rank that owns no frame has no plan at all: plan is None there).
     nccl = gather and world_size > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
     on_device = nccl and (plan is None or isinstance(plan, BatchPlan))
-    if nccl and plan_given:
-        # ... and agreed explicitly where a caller's plan is involved: a rank without frames (plan is None) would pick the
-        # device path while ranks that were handed a frame-by-frame SiftPlan pick the host-staged one -- two different
-        # collective sequences, i.e. a hang.  One 4-byte all-reduce (MIN) of "this rank can take the device path" settles it
-        # for everybody.  (Without a caller's plan every rank builds a BatchPlan or has none: the device path on all of them,
-        # by construction -- no all-reduce, no blocking .item().  `plan_given` must be the same on every rank, as `images` is.)
+    if nccl:
+        # ... and agreed explicitly: a rank without frames (plan is None) would pick the device path while ranks that were
+        # handed a frame-by-frame SiftPlan pick the host-staged one -- two different collective sequences, i.e. a hang; the
+        # same if only some ranks pass a plan.  One 12-byte all-reduce (MIN) settles "every rank can take the device path"
+        # for everybody and shows whether `plan` was given on all ranks or on none (MIN of the flag and of its negation);
+        # every rank takes part whatever it was handed, so a mismatch is an error on every rank instead of a hang on some.
+        # (Cost: one small collective + one .item() per batch, ~30 us beside milliseconds of frames.)
         import torch
-        flag = torch.tensor([1 if on_device else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        flag = torch.tensor([1 if on_device else 0, 1 if plan_given else 0, 0 if plan_given else 1], dtype=torch.int32,
+                            device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        on_device = bool(int(flag.item()))
+        agreed = [int(v) for v in flag.tolist()]
+        if agreed[1] == 0 and agreed[2] == 0:
+            raise RuntimeError("keypoints_batch: `plan` was passed on some ranks and not on others; pass it on every rank or on none")
+        on_device = bool(agreed[0])
     if on_device:
         import torch
         if isinstance(plan, BatchPlan):

@@ -1419,6 +1419,13 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
     for (int g = 0; g < SIFT_GROUPS; g++)
         if (((p->groups_cur >> g) & 1u) && (hc.g_kp[g] > p->grp[g].cap_kp || hc.g_out[g] > p->grp[g].cap_out)) ovf = 1;
     if (hc.n_rec > p->cap_rec) ovf = 1;
+    // ... and so has a candidate list that stayed cut (grow_lists stops at what the reference's rule can admit): the per-scale
+    // counts reference_overflow sees were taken from the cut list, so the cut itself is the evidence
+    for (int g = 0; g < SIFT_GROUPS; g++) {
+        if (!((p->groups_cur >> g) & 1u) || p->grp[g].cap_cand <= 0) continue;
+        for (int o = 0; o < p->n_oct; o++)
+            if (o < SIFT_MAX_OCTAVES && cand_group_of(p, o) == g && hc.n_cand[o] > p->grp[g].cap_cand) ovf = 1;
+    }
     p->records_cut = false;
     if (ovf) { int rc = cap_octaves(p, hc, &n); if (rc) return rc; }
     if (p->profile == 1) {                   // light profile: running totals, read once by the caller's benchmark loop
@@ -1449,6 +1456,9 @@ int plan_run(siftmi_plan *p, const void *image, int32_t image_dtype, int32_t ima
         break;
     }
     if (rc == SIFTMI_ETAILRETRY || rc == SIFTMI_EGROW) rc = SIFTMI_EDEVICE;
+    // A failed enqueue or wait must not leave the plan marked busy: the next call would then report "still has an image in
+    // flight" instead of this error.  Whatever was launched is drained here (the message of `rc` stays the last error).
+    if (rc && p->in_flight) { const std::string keep = g_err; drain_streams(p); g_err = keep; }
     return rc;
 }
 }  // namespace
@@ -2072,6 +2082,10 @@ struct siftmi_matcher {
     int *counter = nullptr;
     hipEvent_t ea = nullptr, eb = nullptr;
     float last_ms = 0;
+    // profile != 0: the events of match.py:226-263 -- "copy H->D KP_1", "copy H->D KP_2", "matching", "copy D->H match" -- as
+    // device times of the last call in ms (-1: the stage did not run: a device-resident list, no pair to copy)
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float stage_ms[4] = {-1.f, -1.f, -1.f, -1.f};
     // ROI mask (MatchPlan.set_roi, match.py:312-320) and the scratch of the masked / mutual variants
     int8_t *roi = nullptr;
     int64_t cap_roi = 0;
@@ -2116,6 +2130,7 @@ int siftmi_match_create(int64_t size, int32_t device_id, int32_t profile, siftmi
     if (!rc) rc = ensure((void **)&m->pairs, &m->cap_pairs, size, sizeof(int2));
     if (!rc && hipMalloc((void **)&m->counter, 16) != hipSuccess) rc = fail(SIFTMI_ENOMEM, "hipMalloc failed");
     if (!rc) { hipEventCreate(&m->ea); hipEventCreate(&m->eb); }
+    if (!rc && profile) for (hipEvent_t &e : m->ev) if (hipEventCreate(&e) != hipSuccess) rc = fail(SIFTMI_EDEVICE, "hipEventCreate failed");
     if (rc) { std::string keep = g_err; siftmi_match_destroy(m); g_err = keep; return rc; }
     *out = m;
     return SIFTMI_OK;
@@ -2134,6 +2149,7 @@ int siftmi_match_destroy(siftmi_matcher *m) {
     if (m->counter) hipFree(m->counter);
     if (m->ea) hipEventDestroy(m->ea);
     if (m->eb) hipEventDestroy(m->eb);
+    for (hipEvent_t e : m->ev) if (e) hipEventDestroy(e);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     return SIFTMI_OK;
@@ -2191,20 +2207,25 @@ int siftmi_match_ex(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, i
     HIPCHK(hipSetDevice(m->device));
     *n_out = 0;
     if (n_total) *n_total = 0;
+    for (float &v : m->stage_ms) v = -1.f;
     if (n1 == 0 || n2 == 0) return SIFTMI_OK;   // dist1 == dist2 == 1e12 -> ratio 1, never < ratio_th
     if (kp1_is_device || kp2_is_device) HIPCHK(hipDeviceSynchronize());
     const uint8_t *d1 = (const uint8_t *)kp1, *d2 = (const uint8_t *)kp2;
     int rc;
+    const bool prof = m->profile && m->ev[0];
+    if (prof) hipEventRecord(m->ev[0], m->stream);
     if (!kp1_is_device) {
         if ((rc = ensure((void **)&m->kp1, &m->cap1, n1, 144))) return rc;
         HIPCHK(hipMemcpyAsync(m->kp1, kp1, (size_t)n1 * 144, hipMemcpyHostToDevice, m->stream));
         d1 = m->kp1;
     }
+    if (prof) hipEventRecord(m->ev[1], m->stream);
     if (!kp2_is_device) {
         if ((rc = ensure((void **)&m->kp2, &m->cap2, n2, 144))) return rc;
         HIPCHK(hipMemcpyAsync(m->kp2, kp2, (size_t)n2 * 144, hipMemcpyHostToDevice, m->stream));
         d2 = m->kp2;
     }
+    if (prof) hipEventRecord(m->ev[2], m->stream);
     // match.py:241-243,252: output capacity = max(self.kpsize, min(n1, n2))
     int64_t cap = m->size;
     if ((n1 < n2 ? n1 : n2) > cap) cap = (n1 < n2 ? n1 : n2);
@@ -2253,9 +2274,22 @@ int siftmi_match_ex(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, i
     int64_t n = count < cap ? count : cap;
     rc = SIFTMI_OK;
     if (n > capacity) { n = capacity; rc = SIFTMI_ECAPACITY; g_err = "pair capacity too small; result truncated"; }
+    if (prof) {
+        m->stage_ms[2] = m->last_ms;
+        if (!kp1_is_device) hipEventElapsedTime(&m->stage_ms[0], m->ev[0], m->ev[1]);
+        if (!kp2_is_device) hipEventElapsedTime(&m->stage_ms[1], m->ev[1], m->ev[2]);
+    }
     if (n > 0) {
         if (!pairs) return fail(SIFTMI_EINVAL, "null pairs buffer");
-        HIPCHK(hipMemcpy(pairs, result, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+        if (prof) {
+            hipEventRecord(m->ev[3], m->stream);
+            HIPCHK(hipMemcpyAsync(pairs, result, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost, m->stream));
+            hipEventRecord(m->ev[4], m->stream);
+            HIPCHK(hipStreamSynchronize(m->stream));
+            hipEventElapsedTime(&m->stage_ms[3], m->ev[3], m->ev[4]);
+        } else {
+            HIPCHK(hipMemcpy(pairs, result, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost));
+        }
     }
     *n_out = n;
     return rc;
@@ -2270,6 +2304,13 @@ int siftmi_match(siftmi_matcher *m, const siftmi_keypoint *kp1, int64_t n1, int3
 int siftmi_match_last_kernel_ms(const siftmi_matcher *m, float *ms) {
     if (!m || !ms) return fail(SIFTMI_EINVAL, "null argument");
     *ms = m->last_ms;
+    return SIFTMI_OK;
+}
+
+int siftmi_match_last_stage_ms(const siftmi_matcher *m, float *ms4) {
+    if (!m || !ms4) return fail(SIFTMI_EINVAL, "null argument");
+    if (!m->profile) return fail(SIFTMI_EINVAL, "the matcher was created without profiling");
+    for (int i = 0; i < 4; i++) ms4[i] = m->stage_ms[i];
     return SIFTMI_OK;
 }
 
@@ -2351,6 +2392,59 @@ int siftmi_stage_blur(int32_t dev, const float *in, float *out, int32_t W, int32
     if (!launch_blur_tiled<false>(g_default_options, 0, a.as<float>(), b.as<float>(), W, H, tp, nullptr))
         launch_blur_generic(0, a.as<float>(), b.as<float>(), t.as<float>(), W, H, tp, nullptr, false);
     if ((rc = stage_end())) return rc;
+    HIPCHK(hipMemcpy(out, b.p, N * 4, hipMemcpyDeviceToHost));
+    return SIFTMI_OK;
+}
+
+// The blur stage with a plan's launch choices exposed, so that a stage test reaches every instance of the marching team
+// kernel (the plain entry point above takes planes below 1400^2 pixels only through the tiled kernel): the normalising
+// instance behind a min/max pass, the typed-frame instances, both workgroup orders, any workgroup count.
+int siftmi_stage_blur_ex(int32_t dev, const void *in, int32_t in_dtype, float *out, int32_t W, int32_t H, const float *taps, int32_t ntaps,
+                         int32_t norm, int32_t xcd_map, int32_t march_wgs, int32_t *kernel_used) {
+    int rc = stage_begin(dev); if (rc) return rc;
+    if (!in || !out || !taps || W < 1 || H < 1) return fail(SIFTMI_EINVAL, "null argument or empty plane");
+    if (ntaps < 1 || ntaps > 64) return fail(SIFTMI_EINVAL, "ntaps must be in 1..64");
+    const size_t esz = dtype_size(in_dtype);
+    if (!esz || in_dtype == SIFTMI_F64) return fail(SIFTMI_EINVAL, "input format %d has no fused blur", in_dtype);
+    if (in_dtype != SIFTMI_F32 && !(norm && ntaps == 15)) return fail(SIFTMI_EINVAL, "typed frames enter through the normalising 15-tap blur only");
+    const size_t N = (size_t)W * H;
+    DevBuf a, b, t, dt, mm;
+    if ((rc = a.upload(in, N * esz)) || (rc = b.alloc(N * 4)) || (rc = t.alloc(N * 4)) || (rc = mm.alloc(8))) return rc;
+    Taps tp; tp.n = ntaps;
+    for (int i = 0; i < ntaps; i++) tp.t[i] = taps[i];
+    if ((rc = dt.upload(tp.t, sizeof tp.t))) return rc;
+    tp.dev = dt.as<float>();
+    Options opt = g_default_options;
+    opt.xcd_map = xcd_map ? 1 : 0;
+    opt.march_wgs = march_wgs > 0 ? march_wgs : 0;
+    uint32_t *mmp = mm.as<uint32_t>();
+    if (norm) {
+        hipLaunchKernelGGL(minmax_init, dim3(1), dim3(1), 0, 0, mmp);
+        if (in_dtype == SIFTMI_F32) {
+            hipLaunchKernelGGL(minmax_kernel, dim3(grid_for((int64_t)N / 4, 256, 2048)), dim3(256), 0, 0, a.as<float>(), (int64_t)N, mmp);
+        } else {
+            SIFTMI_TYPED_DISPATCH(in_dtype, hipLaunchKernelGGL(minmax_typed_kernel<DT>, dim3(grid_for((int64_t)N / TypedChunk<DT>::PX, 256, 256)), dim3(256), 0, 0,
+                                                               (const void *)a.p, (int64_t)N, mmp));
+        }
+    }
+    int used = 0;
+    if (in_dtype != SIFTMI_F32) {
+        bool ok = false;
+        SIFTMI_TYPED_DISPATCH(in_dtype, ok = launch_init_blur_dt<DT>(opt, 0, (const void *)a.p, b.as<float>(), W, H, tp, mmp));
+        if (!ok) return fail(SIFTMI_EINVAL, "no fused blur for input format %d", in_dtype);
+        used = (march_plane(W, H) && taps_symmetric(tp) && opt.march) ? 2 : 1;
+    } else {
+        const int r = norm ? launch_blur_tiled<true>(opt, 0, a.as<float>(), b.as<float>(), W, H, tp, mmp)
+                           : launch_blur_tiled<false>(opt, 0, a.as<float>(), b.as<float>(), W, H, tp, mmp);
+        if (!r) launch_blur_generic(0, a.as<float>(), b.as<float>(), t.as<float>(), W, H, tp, mmp, norm != 0);
+        else {
+            bool marchable = false;
+            for (int n : {11, 15, 17, 21, 27}) marchable = marchable || n == ntaps;
+            used = (march_plane(W, H) && taps_symmetric(tp) && opt.march && marchable) ? 2 : 1;
+        }
+    }
+    if ((rc = stage_end())) return rc;
+    if (kernel_used) *kernel_used = used;
     HIPCHK(hipMemcpy(out, b.p, N * 4, hipMemcpyDeviceToHost));
     return SIFTMI_OK;
 }

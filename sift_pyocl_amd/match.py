@@ -99,6 +99,8 @@ class MatchPlan(object):
             _lib.check(L.siftmi_match_ex(self._handle, p1, n1, dev1, p2, n2, dev2, C.c_float(ratio), mode, int(bool(mutual)),
                                          pairs.ctypes.data, cap, C.byref(n), C.byref(total)), allow=(_lib.ECAPACITY,))
             size = int(n.value)
+            if self.profile:             # match.py:226-263: (label, event) pairs of this call, appended until reset_timer()
+                self.events += self._stage_events()
             match = pairs[:size].copy()
             if raw_results:
                 result = match
@@ -123,6 +125,28 @@ class MatchPlan(object):
         if nbytes % 144:
             raise RuntimeError("device keypoint buffer is not a whole number of 144-byte records")
         return ptr, is_dev, nbytes // 144, keep
+
+    STAGE_LABELS = ("copy H->D KP_1", "copy H->D KP_2", "matching", "copy D->H match")
+
+    def _stage_events(self):
+        """The reference's profiling events of one ``match`` call (match.py:226, 237, 261, 263) with the device time of each
+        stage in place of the pyopencl event: ``evt.profile.end - evt.profile.start`` is nanoseconds, as there.  A stage that
+        did not run (a device-resident list, no pair to copy back) has no entry -- the reference appends none either."""
+        from .plan import StageEvent
+        ms = (C.c_float * 4)()
+        _lib.check(_lib.lib().siftmi_match_last_stage_ms(self._handle, ms))
+        return [(label, StageEvent(v)) for label, v in zip(self.STAGE_LABELS, ms) if v >= 0.0]
+
+    def log_profile(self):
+        """Print the recorded stage times (the reference's classes share this loop: alignment.py:363-375, plan.py:832-846)"""
+        t = 0.0
+        if self.profile:
+            for label, evt in self.events:
+                et = 1e-6 * (evt.profile.end - evt.profile.start)
+                print("%50s:\t%.3fms" % (label, et))
+                t += et
+        print("_" * 80)
+        print("%50s:\t%.3fms" % ("Total execution time", t))
 
     def kernel_ms(self):
         ms = C.c_float()

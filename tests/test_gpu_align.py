@@ -176,3 +176,25 @@ def test_align_rgb_and_extra_and_relative(siftlib, oracle):
     # no keypoints at all -> None, as the reference
     flat = np.zeros_like(ref_img)
     assert la.align(flat) is None
+
+
+def test_align_log_profile_lists_its_own_and_its_plans_events(siftlib, oracle, capsys):
+    """LinearAlign(profile=True).log_profile() (alignment.py:363-375): every entry is (label, event) with the reference's
+    ``1e-6 * (evt.profile.end - evt.profile.start)`` reading; the matcher's stages (match.py:226-263) are among them."""
+    import sift_pyocl_amd as sp
+    big = smooth_noise((420, 460), seed=21, sigma=2.0)
+    ref_img = np.ascontiguousarray(big[10:394, 12:396]); img = np.ascontiguousarray(big[14:398, 9:393])
+    la = sp.LinearAlign(ref_img, profile=True)
+    plain = sp.LinearAlign(ref_img)
+    res = la.align(img, shift_only=True, return_all=True)
+    assert biteq(res["result"], plain.align(img, shift_only=True))              # profiling does not change the result
+    assert [l for l, _ in la.events] == ["transform"]
+    assert "matching" in [l for l, _ in la.match.events] and any("descriptors" in l for l, _ in la.sift.events)
+    for label, evt in la.events + la.match.events + la.sift.events:
+        assert 0 <= evt.profile.end - evt.profile.start < 1e9, label
+    la.log_profile()
+    printed = capsys.readouterr().out
+    for needle in ("transform", "matching", "copy D->H match", "descriptors", "Total execution time"):
+        assert needle in printed, needle
+    plain.log_profile()
+    assert capsys.readouterr().out == ""

@@ -30,10 +30,15 @@ def check_common(d, n_gpus, steps, warmup, scaling="weak"):
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1000 and d["ms_per_step"] > 0
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_pipeline", "achieved_pipeline"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    # SURVEY 8(d)'s whole-call figure under the same key: bytes_alg / kernel time, below the dominant kernel's own fraction
+    assert 0.02 < r["frac_pipeline"] < r["frac"]
+    if n_gpus > 1:
+        m = d["ms_per_step_ranks"]
+        assert len(m["per_rank"]) == n_gpus and m["min"] <= m["max"] and abs(m["max"] - d["ms_per_step"]) / d["ms_per_step"] < 0.02
 
 
 def test_bench_single_gpu_line():
@@ -46,6 +51,7 @@ def test_bench_single_gpu_line():
     # value is throughput of K steps of one 4096 x 4096 image: consistent with ms_per_step
     assert abs(d["value"] - 4096 * 4096 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
     assert "blur_team_kernel" in d["roofline"]["kernel"] and "cpu" in c
+    assert abs(d["roofline"]["frac_pipeline"] - d["roofline_pipeline"]["frac"]) < 1e-9 and "frac_rocprof" in d["roofline"]
     for key in ("pipelined", "host_to_host", "match_100k"):
         assert key in d and "error" not in d[key], (key, d.get(key))
     assert d["match_100k"]["pairs"] == d["match_100k"]["expected_pairs"]
@@ -81,6 +87,7 @@ def test_bench_c4_sharded_batch():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["name"] == "c4" and d["config"]["images_per_step"] == 64
     assert 1500 < d["config"]["keypoints_per_image"] < 4000          # ~2.7 k per 2048^2 white-noise frame
     assert abs(d["value"] - 64 * 2048 * 2048 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    assert 0.0 < d["roofline"]["frac_pipeline"] < 1.0 and d["roofline"]["bound"] == "hbm" and len(d["ms_per_step_ranks"]["per_rank"]) == 2
     one = run([sys.executable, "bench.py", "--config", "c4", "--steps", "1", "--warmup", "1"], timeout=900)
     assert one["n_gpus"] == 1 and abs(one["config"]["keypoints_per_image"] - d["config"]["keypoints_per_image"]) < 1e-6
 

@@ -166,6 +166,57 @@ def test_blur_bit_exact(siftlib, oracle, shape, ntaps):
     assert np.array_equal(out.view(np.uint32), exp.view(np.uint32))
 
 
+# The marching team kernel (blur_team_kernel: planes of at least 1400^2 pixels, i.e. every full-resolution launch of the headline
+# frame) reached AS A STAGE: shapes with a partial last strip, an odd width (scalar stores), a height that is no multiple of
+# the segment height; both workgroup orders; workgroup counts that give other segment heights / last sub-block counts.
+TEAM_SHAPES = [(1408, 1536), (1026, 2050), (1537, 1301)]
+
+
+@pytest.mark.parametrize("shape", TEAM_SHAPES)
+@pytest.mark.parametrize("ntaps", [11, 15, 17, 21, 27])
+def test_blur_team_kernel_bit_exact(siftlib, oracle, shape, ntaps):
+    H, W = shape
+    img = white_noise(shape, seed=100 + ntaps) * 255
+    taps = oracle.gaussian_taps(ntaps / 8.0, ntaps)
+    exp = oracle.blur(img, taps)
+    for xcd_map, wgs in [(1, 0), (0, 0), (1, 300), (1, 1500)]:
+        out = np.empty_like(img)
+        used = C.c_int32(-1)
+        assert siftlib.siftmi_stage_blur_ex(0, _p(img), 0, _p(out), W, H, _p(taps), ntaps, 0, xcd_map, wgs, C.byref(used)) == 0
+        assert used.value == 2, "the plane did not reach blur_team_kernel"
+        bad = np.argwhere(out.view(np.uint32) != exp.view(np.uint32))
+        assert bad.size == 0, (ntaps, xcd_map, wgs, len(bad), bad[:4])
+
+
+@pytest.mark.parametrize("shape", TEAM_SHAPES)
+def test_blur_team_kernel_normalising_and_typed_instances(siftlib, oracle, shape):
+    """blur_team_kernel<15, NORM = true, S, DT>: `normalizes` (preprocess.cl:239-252) applied while staging, behind the min/max
+    pass; DT != 0: the integer / RGB converters (preprocess.cl:53-223) at the point of use."""
+    H, W = shape
+    taps = oracle.gaussian_taps(float(np.sqrt(1.6 ** 2 - 0.25)), 15)
+    rng = np.random.default_rng(H)
+    f32 = (white_noise(shape, seed=7) - 0.25) * 3000.0
+    u8 = rng.integers(0, 256, shape, dtype=np.uint8)
+    u16 = rng.integers(0, 65536, shape, dtype=np.uint16)
+    i64 = rng.integers(-2 ** 62, 2 ** 62, shape, dtype=np.int64)
+    rgb = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    r, g, b = (rgb[..., c].astype(np.float32) for c in range(3))
+    rgb32 = (np.float32(0.299) * r + np.float32(0.587) * g) + np.float32(0.114) * b
+    cases = [("f32", 0, f32, f32), ("u8", 1, u8, u8.astype(np.float32)), ("u16", 2, u16, u16.astype(np.float32)),
+             ("i64", 6, i64, i64.astype(np.float32)), ("rgb8", 8, rgb, rgb32)]
+    for name, code, frame, as32 in cases:
+        as32 = np.ascontiguousarray(as32, np.float32)
+        exp = oracle.blur(oracle.normalize(as32, as32.min(), as32.max()), taps)
+        for xcd_map in (1, 0):
+            out = np.empty(shape, np.float32)
+            used = C.c_int32(-1)
+            frame = np.ascontiguousarray(frame)
+            assert siftlib.siftmi_stage_blur_ex(0, _p(frame), code, _p(out), W, H, _p(taps), 15, 1, xcd_map, 0, C.byref(used)) == 0, name
+            assert used.value == 2, name
+            bad = np.argwhere(out.view(np.uint32) != exp.view(np.uint32))
+            assert bad.size == 0, (name, xcd_map, len(bad), bad[:4])
+
+
 def test_minmax_normalize(siftlib, oracle):
     for shape in [(512, 512), (131, 97), (1980, 2560)]:
         img = (white_noise(shape, 1) - 0.3) * 1000
@@ -478,6 +529,43 @@ def test_match_bit_exact(siftlib, oracle, n1, n2):
     assert np.array_equal(sort_rows(got), sort_rows(exp))
     rec = mp.match(a, b)
     assert rec.shape == (len(got), 2) and rec.dtype == mp.dtype_kp
+
+
+def test_match_events_under_profile(siftlib, oracle, capsys):
+    """MatchPlan.events as the reference fills it under profile=True (match.py:226, 237, 261, 263; reset at :305-310):
+    (label, event) pairs whose ``profile.end - profile.start`` is the stage's device time in ns."""
+    import sift_pyocl_amd as sp
+    a, b = _random_kp(3000, 11), _random_kp(2500, 12)
+    b["desc"][:500] = a["desc"][:500]
+    mp = sp.MatchPlan(profile=True)
+    got = mp.match(a, b, raw_results=True)
+    exp, total = oracle.match(a, b)
+    assert total == len(got) >= 500 and np.array_equal(sort_rows(got), sort_rows(exp))      # profiling does not change the result
+    assert [l for l, _ in mp.events] == ["copy H->D KP_1", "copy H->D KP_2", "matching", "copy D->H match"]
+    for label, evt in mp.events:
+        ns = evt.profile.end - evt.profile.start
+        assert 0 < ns < 1e9, (label, ns)
+    assert abs(dict(mp.events)["matching"].ms - mp.kernel_ms()) < 1e-6
+    mp.match(a, b)
+    assert len(mp.events) == 8                     # the reference appends call after call
+    mp.log_profile()
+    printed = capsys.readouterr().out
+    assert "matching" in printed and "copy D->H match" in printed and "Total execution time" in printed
+    mp.reset_timer()
+    assert mp.events == []
+    # a device-resident list has no H->D copy; nothing to copy back when nothing matches
+    plan = sp.SiftPlan(template=smooth_noise((256, 256)))
+    kp = plan.keypoints(smooth_noise((256, 256)))
+    mp.match(kp, plan.device_records(), raw_results=True)
+    assert [l for l, _ in mp.events] == ["copy H->D KP_1", "matching", "copy D->H match"]
+    mp.reset_timer()
+    far = _random_kp(50, 13)
+    far["desc"][:] = 255 - _random_kp(50, 14)["desc"] // 8
+    none = mp.match(_random_kp(40, 15), far[:1], raw_results=True)          # a single list element: dist2 stays at its initial value
+    assert [l for l, _ in mp.events][:3] == ["copy H->D KP_1", "copy H->D KP_2", "matching"] and len(mp.events) == 3 + (len(none) > 0)
+    plain = sp.MatchPlan()
+    plain.match(a, b)
+    assert plain.events == []
 
 
 def test_match_real_keypoints(siftlib, oracle):

@@ -124,6 +124,8 @@ if nb and nw:
            "write_size_bytes_per_launch": wb / nw,
            "traffic_bytes_per_launch": 2.0 * fb / nb + wb / nw,
            "calibration": {"minmax_kernel_fetch_KiB_reported": sum(cal) / max(len(cal), 1), "expected_KiB": image_pixels * 4 // 1024},
-           "rocprof_avg_launch_us_all_blur_launches": fam["blur (all instances)"][1] / fam["blur (all instances)"][0] / 1e3}
+           "rocprof_avg_launch_us_all_blur_launches": fam["blur (all instances)"][1] / fam["blur (all instances)"][0] / 1e3,
+           # the launches bench.py's roofline brackets, from the kernel trace of the --stats pass (bench.py: roofline.frac_rocprof)
+           "rocprof_avg_launch_us_full_resolution": (b0_t / b0_n) if b0_n else None, "rocprof_full_resolution_launches": b0_n}
     print("\n== blur family traffic per launch (corrected):", json.dumps(out))
     json.dump(out, open(os.path.join(d, "blur_traffic.json"), "w"), indent=1)

@@ -95,7 +95,7 @@ int siftmi_plan_capacity(const siftmi_plan *plan, int64_t *records, int64_t *gro
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
- *   launch shapes      "march", "march_wgs", "xcd_map" (marching blur, extrema: every XCD takes a contiguous range of tiles; default 1), "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
+ *   launch shapes      "march", "march_wgs", "xcd_map" (marching blur, extrema: every XCD takes a contiguous range of tiles; default 1), "march_prio" (marching blur of 15 taps and more: wave priority falls with a workgroup's progress; default 1), "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
  *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks", "desc_early_blocks",
  *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_stream", "maps_blocks"
  *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",
@@ -245,7 +245,8 @@ int siftmi_stage_blur(int32_t device_id, const float *in, float *out, int32_t W,
 /* the same stage with a plan's launch choices exposed (test hook for the large-plane kernels): `in` holds a frame of
  * `in_dtype` (SIFTMI_F32, or an integer / RGB8 code: those enter through the normalising 15-tap blur only, as in a plan);
  * norm != 0: min/max of the frame first (reductions.cl:62-241), then the blur with `normalizes` (preprocess.cl:239-252)
- * applied to its inputs; xcd_map: workgroup order of the marching kernel; march_wgs: its workgroup count (0: default);
+ * applied to its inputs; xcd_map: bit 0 = workgroup order of the marching kernel (option "xcd_map"), bit 1 set = its priority
+ * feedback off (option "march_prio" 0); march_wgs: its workgroup count (0: default);
  * *kernel_used (may be null): 0 generic two-pass, 1 tiled kernel, 2 marching team kernel. */
 int siftmi_stage_blur_ex(int32_t device_id, const void *in, int32_t in_dtype, float *out, int32_t W, int32_t H,
                          const float *taps, int32_t ntaps, int32_t norm, int32_t xcd_map, int32_t march_wgs,

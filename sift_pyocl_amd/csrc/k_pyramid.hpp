@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
                                                           int W, int H, int nblocks, int last_subs, int rows_out,
                                                           TapsArg<N> taps, const uint32_t *__restrict__ mm,
                                                           float *__restrict__ next0,     // not null: also out[2y][2x] -> next0 (the next octave's plane 0)
-                                                          int xcd_map) {
+                                                          int xcd_map, int prio) {
     constexpr int NT = 128;                       // threads per team
     using G = March2Geom<N, NT, S>;
     using SS = SubSplit<N, S>;
@@ -591,6 +591,28 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
     }
     __syncthreads();
     int g = 0;                                     // step counter: buffer of step g is g % 3
+    // Wave priority as negative feedback on progress (prio != 0).  The whole grid is resident at once and the SIMD arbiter serves
+    // the OLDEST wave first: of the three workgroups of a CU the first one marches as if it were alone (its own step latency,
+    // the SIMDs two thirds idle), the second gets what it leaves, and the third does most of its march alone at the end -- a
+    // traced 27-tap launch: they end at 54 / 76 / 100 % of its time (tools/ubench/blur_var.hip, profiles/r06/blur_timeline.txt).
+    // Every wave lowers its priority by one level per quarter of its march: a workgroup that is behind outranks one that is
+    // ahead, the three advance together and end within 16 % of one another: 27 / 21 / 17 / 15 taps -8 / -6 / -5 / -4.5 % per
+    // launch alone (11 taps: +1-2 % alone, -1 % inside a frame).  Thirds, eighths, levels dithered from step to step, a short
+    // last phase: all worse than quarters.  s_setprio only orders waves that compete for the same SIMD; which launches ask for
+    // it: siftmi.hip, launch_team.
+    const int total_steps = (nblocks - 1) * S + last_subs;
+    int prio_level = -1;
+    auto set_prio = [&](int step) {
+        if (!prio) return;
+        const int q = (step * 4) / total_steps;    // quarter of the march this workgroup is in
+        if (q == prio_level) return;
+        prio_level = q;
+        if (q <= 0) __builtin_amdgcn_s_setprio(3);
+        else if (q == 1) __builtin_amdgcn_s_setprio(2);
+        else if (q == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    };
+    set_prio(0);
     // Each team runs its own copy of the step loop (same barrier count).  With one loop and a role test inside, the V team's
     // accumulators and look-ahead registers are live across the H team's code; apart, the H team's window registers and the V
     // team's state share one allocation (27 taps: 34 -> 6 spilled SGPRs, 17 taps: 96 -> 88 VGPRs; whole call -0.8 %).
@@ -602,6 +624,7 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
                 hpass(sbase + (g % 3) * BUF, SS::pairs(sub));
                 __syncthreads();
                 g++;
+                set_prio(g);
             }
         }
         return;
@@ -626,6 +649,7 @@ __global__ __launch_bounds__(64 * HW + 128) void blur_team_kernel(const void *__
             }
             __syncthreads();
             g++;
+            set_prio(g);
         }
     }
     // ---- epilogue: vertical march of the last step, (nblocks - 1, last_subs - 1)

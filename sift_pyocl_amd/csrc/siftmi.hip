@@ -106,6 +106,8 @@ struct Options {
     int march = 1;           // marching blur for large planes (0: tiled blur everywhere)
     int march_wgs = 0;       // workgroups wanted by the marching blur (0: 1024, 768 for 27 taps)
     int xcd_map = 1;         // marching blur: whole segment rows per XCD (k_pyramid.hpp: the strips' halo columns become L2 hits)
+    int march_prio = 1;      // marching blur: wave priority falls by one level per quarter of a workgroup's march, so that the workgroups of a CU
+                             // advance together instead of oldest first (k_pyramid.hpp: set_prio): 0 never, 1 by launch_team's rule, 2 every launch
     int ori_blocks = 4096, ori_pad = 0;      // orientation launch: workgroups (upper bound; the kernel cuts it down by the group's count)
     // descriptor launch: workgroups (keypoints are handed out dynamically, so a workgroup stays until the group is done:
     // 1024 = every wave slot of the chip, which starves the other stream's kernels for the whole launch -- 1024^2 smooth
@@ -373,8 +375,15 @@ void launch_team(const Options &opt, hipStream_t st, const void *in, float *out,
     while (covered(b, m) < need) m++;                // m <= S
     const int nblocks = b + (m > 0 ? 1 : 0), last_subs = m > 0 ? m : S;
     dim3 grid((unsigned)gx, (unsigned)gy);
+    // priority feedback (k_pyramid.hpp: set_prio), option march_prio: 1 = where a CU holds about three or more workgroups of the
+    // launch (704 of them: the workgroups of a CU then advance together instead of oldest first), 2 = every launch (launch_blur
+    // asks for it on the later octaves' chains, whose launches run beside octave 0's per-keypoint kernels and end the frame:
+    // their waves outrank those), 0 = never.  Interleaved A/B, whole calls, off -> on: 4096^2 with 3 / 9 octaves 0.800 -> 0.766 /
+    // 0.903 -> 0.865 ms, 3000^2 0.624 -> 0.610, 16384^2 10.47 -> 10.2 (its full-resolution launches 597 -> 530 us), smoothed
+    // 4096^2 4.28 -> 4.22.  Octave 0 of a 2048^2 frame (536 workgroups) loses 3 % with it and keeps the arbiter's order.
+    const int prio = (opt.march_prio == 2 || (opt.march_prio == 1 && gx * gy >= 704)) ? 1 : 0;
     launch_ev(stop, blur_team_kernel<N, NORM, S, DT>, grid, dim3(256), (size_t)3 * G::LDS_BYTES, st, in, out, W, H, nblocks, last_subs,
-              rows_out, ta, mm, half, opt.xcd_map);
+              rows_out, ta, mm, half, opt.xcd_map, prio);
 }
 
 // Large planes: the team form, with the sub-block count and workgroup count that measured best per tap count on a 4096^2
@@ -437,8 +446,10 @@ void launch_blur_generic(hipStream_t st, const float *in, float *out, float *tmp
 bool launch_blur(siftmi_plan *p, const float *in, float *out, int W, int H, const Taps &t, bool norm, hipStream_t st = nullptr, float *half = nullptr,
                  hipEvent_t stop = nullptr) {
     if (!st) st = p->stream;
-    const int r = norm ? launch_blur_tiled<true>(p->opt, st, in, out, W, H, t, p->mm, half, stop)
-                       : launch_blur_tiled<false>(p->opt, st, in, out, W, H, t, p->mm, half, stop);
+    Options opt = p->opt;
+    if (opt.march_prio == 1 && st != p->stream) opt.march_prio = 2;      // a later octave's chain (launch_team)
+    const int r = norm ? launch_blur_tiled<true>(opt, st, in, out, W, H, t, p->mm, half, stop)
+                       : launch_blur_tiled<false>(opt, st, in, out, W, H, t, p->mm, half, stop);
     if (!r) {       // one intermediate plane per stream that builds pyramids: the chains run beside one another
         float *tmp = (st == p->stream2 && p->tmp_below) ? p->tmp_below : ((st == p->stream3 && p->tmp_later) ? p->tmp_later : p->tmp);
         launch_blur_generic(st, in, out, tmp, W, H, t, p->mm, norm);
@@ -981,6 +992,7 @@ int siftmi_plan_set_option(siftmi_plan *p, const char *name, int64_t value) {
     else if (n == "march") o.march = v != 0;
     else if (n == "march_wgs") o.march_wgs = v > 0 ? v : 0;
     else if (n == "xcd_map") o.xcd_map = v != 0;
+    else if (n == "march_prio") { if (v < 0 || v > 2) return fail(SIFTMI_EINVAL, "march_prio must be 0, 1 or 2"); o.march_prio = (int)v; }
     else if (n == "ori_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "ori_blocks must be >= 1"); o.ori_blocks = v; }
     else if (n == "ori_pad") o.ori_pad = v > 0 ? v : 0;
     else if (n == "desc_blocks") { if (v < 1) return fail(SIFTMI_EINVAL, "desc_blocks must be >= 1"); o.desc_blocks = v; }
@@ -2415,7 +2427,8 @@ int siftmi_stage_blur_ex(int32_t dev, const void *in, int32_t in_dtype, float *o
     if ((rc = dt.upload(tp.t, sizeof tp.t))) return rc;
     tp.dev = dt.as<float>();
     Options opt = g_default_options;
-    opt.xcd_map = xcd_map ? 1 : 0;
+    opt.xcd_map = (xcd_map & 1) ? 1 : 0;
+    opt.march_prio = (xcd_map & 2) ? 0 : 2;       // (forced where not off: the stage planes are smaller than the rule's)
     opt.march_wgs = march_wgs > 0 ? march_wgs : 0;
     uint32_t *mmp = mm.as<uint32_t>();
     if (norm) {

@@ -179,7 +179,7 @@ def test_blur_team_kernel_bit_exact(siftlib, oracle, shape, ntaps):
     img = white_noise(shape, seed=100 + ntaps) * 255
     taps = oracle.gaussian_taps(ntaps / 8.0, ntaps)
     exp = oracle.blur(img, taps)
-    for xcd_map, wgs in [(1, 0), (0, 0), (1, 300), (1, 1500)]:
+    for xcd_map, wgs in [(1, 0), (0, 0), (1, 300), (1, 1500), (3, 0), (2, 500)]:       # (bit 1 of xcd_map: priority feedback off)
         out = np.empty_like(img)
         used = C.c_int32(-1)
         assert siftlib.siftmi_stage_blur_ex(0, _p(img), 0, _p(out), W, H, _p(taps), ntaps, 0, xcd_map, wgs, C.byref(used)) == 0

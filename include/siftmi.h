@@ -92,6 +92,10 @@ int siftmi_plan_info(const siftmi_plan *plan, int32_t *n_octaves, int64_t *kpsiz
  * The device lists start at kpsize entries and grow when an image needs more (it is then run again inside the same call):
  * siftmi_plan_capacity reports the record list's current size and how often a list has grown. */
 int siftmi_plan_capacity(const siftmi_plan *plan, int64_t *records, int64_t *growths);
+/* How often the one-launch form of the small octaves (a workgroup per octave, chained through a flag with a bounded wait) gave up
+ * waiting and the image ran again octave by octave -- the result is the same either way, the plan keeps the per-octave launches
+ * from then on (*tail_enabled 0).  No reference counterpart: the reference launches every octave's kernels one by one. */
+int siftmi_plan_tail_timeouts(const siftmi_plan *plan, int64_t *timeouts, int32_t *tail_enabled);
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
@@ -181,6 +185,8 @@ int siftmi_batch_create(int32_t height, int32_t width, int32_t in_dtype, int32_t
 int siftmi_batch_destroy(siftmi_batch *batch);
 int siftmi_batch_set_params(siftmi_batch *batch, const siftmi_params *params);
 int siftmi_batch_info(const siftmi_batch *batch, int32_t *lanes, int64_t *bytes_allocated);
+/* siftmi_plan_tail_timeouts summed over the lanes; *lanes_with_tail: lanes that still use the one-launch form */
+int siftmi_batch_tail_timeouts(const siftmi_batch *batch, int64_t *timeouts, int32_t *lanes_with_tail);
 /* light profiling of the lanes (level 1: one hipEvent pair around the full-resolution blur launches of every frame, as
  * siftmi_plan_create's profile = 1); siftmi_batch_blur_ms returns their sum over the frames of the last batch */
 int siftmi_batch_set_profile(siftmi_batch *batch, int32_t level);

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "siftmi_plan_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "siftmi_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "siftmi_plan_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "siftmi_plan_tail_timeouts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "siftmi_batch_tail_timeouts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "siftmi_host_pool_limit": (C.c_int, [C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "siftmi_host_pool_trim": (C.c_int, [C.c_int64]),
     "siftmi_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),

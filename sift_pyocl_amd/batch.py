@@ -62,6 +62,12 @@ class BatchPlan(SiftPlan):
         """SiftPlan.set_option on every lane (``siftmi_batch_set_option``); results never depend on an option."""
         _lib.check(_lib.lib().siftmi_batch_set_option(self._handle, str(name).encode(), int(value)))
 
+    def tail_timeouts(self):
+        """(re-runs after a time-out of the small octaves' one-launch form, lanes that still use it): see SiftPlan.tail_timeouts"""
+        n, on = C.c_int64(), C.c_int32()
+        _lib.check(_lib.lib().siftmi_batch_tail_timeouts(self._handle, C.byref(n), C.byref(on)))
+        return int(n.value), int(on.value)
+
     def blur_times(self):
         """profile='light': hipEvent time, launches and pixels of the full-resolution blur launches of the last batch"""
         ms = C.c_double(); nl = C.c_int64(); px = C.c_double()

@@ -250,6 +250,7 @@ struct siftmi_plan {
     bool in_flight = false;       // an image has been enqueued and not yet waited for (plan_wait) or drained
     bool records_cut = false;     // the last image hit the reference's per-octave capacity and was cut to it (cap_octaves): a pinned result array is stale
     int64_t grows = 0;            // list growths since creation (each one ran its image again)
+    int64_t tail_timeouts = 0;    // images whose tail launch gave up waiting for the octave above and ran again (0 or 1: the plan then drops the tail launch)
     KpRecord *host_out = nullptr; // pinned result array of the call being enqueued (zero-copy delivery), or null
     int host_cap = 0;
     bool desc_rows = true;        // descriptor windows fit the row tables of descriptor_kernel (R <= SIFT_DESC_MAXRAD for this init_sigma)
@@ -966,6 +967,13 @@ int siftmi_plan_capacity(const siftmi_plan *p, int64_t *records, int64_t *growth
     return SIFTMI_OK;
 }
 
+int siftmi_plan_tail_timeouts(const siftmi_plan *p, int64_t *timeouts, int32_t *tail_enabled) {
+    if (!p) return fail(SIFTMI_EINVAL, "null plan");
+    if (timeouts) *timeouts = p->tail_timeouts;
+    if (tail_enabled) *tail_enabled = p->opt.tail ? 1 : 0;
+    return SIFTMI_OK;
+}
+
 int siftmi_plan_set_params(siftmi_plan *p, const siftmi_params *params) {
     if (!p || !params) return fail(SIFTMI_EINVAL, "null argument");
     if (params->pix_per_kp != p->par.pix_per_kp || params->octave_max != p->par.octave_max)
@@ -1412,6 +1420,7 @@ int plan_wait(siftmi_plan *p, int64_t *n_out, int32_t *overflow) {
         // a workgroup of octave_tail_kernel stopped waiting for the octave above (k_tail.hpp): this image is incomplete.
         // From now on the plan walks the small octaves with the per-octave launches; the caller runs the image again.
         p->opt.tail = 0;
+        p->tail_timeouts++;
         drain_streams(p);
         return fail(SIFTMI_ETAILRETRY, "octave_tail_kernel timed out waiting for the previous octave; tail launches disabled for this plan");
     }
@@ -1745,6 +1754,15 @@ int siftmi_batch_info(const siftmi_batch *b, int32_t *lanes, int64_t *bytes_allo
         for (const siftmi_plan *p : b->lanes) t += p->bytes;
         *bytes_allocated = t;
     }
+    return SIFTMI_OK;
+}
+
+int siftmi_batch_tail_timeouts(const siftmi_batch *b, int64_t *timeouts, int32_t *lanes_with_tail) {
+    if (!b) return fail(SIFTMI_EINVAL, "null batch");
+    int64_t t = 0; int32_t on = 0;
+    for (const siftmi_plan *p : b->lanes) { t += p->tail_timeouts; on += p->opt.tail ? 1 : 0; }
+    if (timeouts) *timeouts = t;
+    if (lanes_with_tail) *lanes_with_tail = on;
     return SIFTMI_OK;
 }
 

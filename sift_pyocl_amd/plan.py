@@ -369,6 +369,13 @@ class SiftPlan(object):
         _lib.check(_lib.lib().siftmi_plan_capacity(self._handle, C.byref(rec), C.byref(grows)))
         return int(rec.value), int(grows.value)
 
+    def tail_timeouts(self):
+        """(images that ran again because the one-launch form of the small octaves timed out, whether the plan still uses that
+        form).  The wait between its workgroups is bounded; a time-out costs one re-run and never a wrong result."""
+        n, on = C.c_int64(), C.c_int32()
+        _lib.check(_lib.lib().siftmi_plan_tail_timeouts(self._handle, C.byref(n), C.byref(on)))
+        return int(n.value), bool(on.value)
+
     def device_records(self):
         """The records of the last keypoints() call where they lie on the device (no copy): an object with
         ``__cuda_array_interface__`` (uint8, n * 144 bytes), accepted by ``MatchPlan.match``.  Valid until the next

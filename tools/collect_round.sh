@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box (from the repo root):  bash tools/collect_round.sh r03
 # -> gpurun_out/round_<tag>/ ; copy what should be judged into profiles/<tag>/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd)
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -118,6 +118,20 @@ template <int N, int S> void prio(const float *in, float *o2, int W, int H, cons
            same ? "bitwise equal" : "MISMATCH");
 }
 
+template <int N, int S, int LP> void ldspitch(const float *in, float *o2, int W, int H, const TapsArg<N> &ta, int wgs, float t_ref, int prio) {
+    using G = March2Geom<N, 128, S>;
+    const Geo g = geometry<N, S>(W, H, wgs);
+    const size_t lds = (size_t)3 * G::NPS * (G::PITCH + (LP ? 2 : 0)) * 2 * 4;
+    hipMemset(o2, 0xff, (size_t)W * H * 4);
+    auto launch = [&] { hipLaunchKernelGGL((blur_team_x<N, false, S, 0, 2, 0, 0, LP>), dim3(g.gx, g.gy), dim3(256), lds, 0, (const void *)in, o2, W, H, g.nblocks,
+                                           g.last_subs, g.rows_out, ta, (const uint32_t *)nullptr, (float *)nullptr, 1, prio, 0, 0, (unsigned long long *)nullptr, 0); };
+    const float t = timeit(launch);
+    size_t bad;
+    const bool same = same_as_ref(o2, (size_t)W * H, &bad);
+    printf("  N %2d  product (prio %d)%s   wgs %4d  %7.2f us  (%+5.1f %%)  %s\n", N, prio, LP ? " + conflict-free H reads (pitch 16 mod 32, two row pairs per wave)" : "", g.gx * g.gy, t,
+           100.0 * (t - t_ref) / t_ref, same ? "bitwise equal" : "MISMATCH");
+}
+
 template <int N, int S> void stagger(const float *in, float *o2, int W, int H, const TapsArg<N> &ta, int wgs, float t_ref, int mode, int units) {
     using G = March2Geom<N, 128, S>;
     const Geo g = geometry<N, S>(W, H, wgs);
@@ -166,18 +180,27 @@ template <int N, int S> void timeline(const float *in, float *o2, int W, int H, 
     printf("  workgroups per CU (by HW_ID): ");
     for (auto &kv : hist) printf("%d CUs with %d;  ", kv.second, kv.first);
     printf("\n");
-    // launch-wide: when do the workgroups start and end (per XCD: every XCD counts its own clock)
-    for (int xcd = 0; xcd < 8; xcd += 7) {
-        std::vector<unsigned long long> st, en;
-        for (int wg = xcd; wg < nwg; wg += 8) for (int w = 0; w < 4; w++) {
-            const unsigned long long *e = &tr[((size_t)wg * 4 + w) * TRN];
-            const int n = (int)std::min<unsigned long long>(e[1], TRN);
-            if (n > 3) { st.push_back(e[2]); en.push_back(e[n - 1]); }
+    // launch-wide, on the chip-wide 100 MHz clock (s_memrealtime): when do the waves start and end, XCD by XCD
+    {
+        unsigned long long z = ~0ull, zend = 0;
+        for (int wg = 0; wg < nwg; wg++) for (int w = 0; w < 4; w++) { const unsigned long long *e = &tr[((size_t)wg * 4 + w) * TRN]; if (e[1] > 3) { z = std::min(z, e[TRN - 2]); zend = std::max(zend, e[TRN - 1]); } }
+        printf("  chip: first wave start -> last wave end %.2f us (launch period in the train %.2f us)\n", (zend - z) / 100.0, t);
+        {   // shader clock seen by the waves: cycles between a wave's first and last mark over its 100 MHz time from start to end
+            double cyc = 0, us = 0;
+            for (int wg = 0; wg < nwg; wg += 7) { const unsigned long long *e = &tr[((size_t)wg * 4 + 2) * TRN]; const int n = (int)std::min<unsigned long long>(e[1], TRN);
+                if (n > 3) { cyc += (double)(e[n - 1] - e[2]); us += (e[TRN - 1] - e[TRN - 2]) / 100.0; } }
+            printf("  shader clock while the launch runs: %.0f MHz (V waves: cycles first -> last mark / their 100 MHz start -> end time)\n", cyc / us);
         }
-        std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
-        const unsigned long long z = st[0];
-        printf("  XCD %d: wave starts (first mark) min 0, median %llu, max %llu | wave ends min %llu, 10 %% %llu, median %llu, 90 %% %llu, max %llu  (launch period %.0f cycles at 2.4 GHz)\n", xcd,
-               st[st.size() / 2] - z, st.back() - z, en[0] - z, en[en.size() / 10] - z, en[en.size() / 2] - z, en[en.size() * 9 / 10] - z, en.back() - z, t * 2400.0);
+        for (int xcd = 0; xcd < 8; xcd++) {
+            std::vector<double> st, en;
+            for (int wg = xcd; wg < nwg; wg += 8) for (int w = 0; w < 4; w++) {
+                const unsigned long long *e = &tr[((size_t)wg * 4 + w) * TRN];
+                if (e[1] > 3) { st.push_back((e[TRN - 2] - z) / 100.0); en.push_back((e[TRN - 1] - z) / 100.0); }
+            }
+            std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+            printf("    XCD %d: starts %.2f / %.2f / %.2f us (min / median / max) | ends %.2f / %.2f / %.2f / %.2f / %.2f us (min / 10 %% / median / 90 %% / max)\n", xcd,
+                   st[0], st[st.size() / 2], st.back(), en[0], en[en.size() / 10], en[en.size() / 2], en[en.size() * 9 / 10], en.back());
+        }
     }
     auto cu_it = by_cu.begin();
     for (auto it = by_cu.begin(); it != by_cu.end(); ++it) if (it->second.size() == (N >= 27 ? 3u : 4u)) { cu_it = it; break; }
@@ -264,7 +287,8 @@ template <int N, int S> void run(const float *in, float *o1, float *o2, int W, i
     if (which & 4) {
         variant<N, S, 2, 2>("front loads, D=2, clock", in, o2, W, H, ta, wgs0, t_ref);
     }
-    if (which & 256) { for (int mode : {0, 1, 9, 10, 1, 9, 10, 0}) prio<N, S>(in, o2, W, H, ta, wgs0, t_ref, mode); }
+    if (which & 512) { for (int rep = 0; rep < 2; rep++) { ldspitch<N, S, 0>(in, o2, W, H, ta, wgs0, t_ref, 1); ldspitch<N, S, 1>(in, o2, W, H, ta, wgs0, t_ref, 1); } }
+    if (which & 256) { for (int mode : {0, 1, 15, 14, 11, 12, 13, 16, 1, 15, 14, 11, 12, 13, 16}) prio<N, S>(in, o2, W, H, ta, wgs0, t_ref, mode); }
     if (which & 128) { timeline<N, S>(in, o2, W, H); if (which & 256) timeline<N, S>(in, o2, W, H, 1); }
     if (which & 64) occupancy<N, S>(in, o1, W, H);
     if (which & 32) {

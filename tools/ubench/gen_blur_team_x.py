@@ -65,10 +65,11 @@ assert old in k
 k = k.replace(old, old + """    constexpr int TRN = 160;                   // marks per wave
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(sbase + 3 * BUF) + (threadIdx.x >> 6) * TRN;
     int ti = 2;
+    if (TR && (threadIdx.x & 63) == 0) tl[TRN - 2] = __builtin_amdgcn_s_memrealtime();      // the chip-wide 100 MHz clock at the wave's start ...
 #define TMARK() do { if (TR) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && ti < TRN) tl[ti] = t_; ti++; } } while (0)
 #define TDUMP() do { if (TR && trace) { __builtin_amdgcn_wave_barrier(); if ((threadIdx.x & 63) == 0) { \\
         tl[0] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) | ((unsigned long long)role << 32) | ((unsigned long long)(blockIdx.x + gridDim.x * blockIdx.y) << 40); \\
-        tl[1] = (unsigned long long)ti; } __builtin_amdgcn_wave_barrier(); \\
+        tl[1] = (unsigned long long)ti; tl[TRN - 1] = __builtin_amdgcn_s_memrealtime(); } __builtin_amdgcn_wave_barrier(); \\
         unsigned long long *dst_ = trace + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * TRN; \\
         for (int e_ = threadIdx.x & 63; e_ < TRN; e_ += 64) dst_[e_] = tl[e_]; } } while (0)
 """, 1)
@@ -112,6 +113,13 @@ k = k.replace(old, old + """    const int Tsteps_x = (nblocks - 1) * S + last_su
             const int body = Tsteps_x - last;
             q = gg >= body ? 3 : (gg * 3) / body;
         }
+        if (prio_mode >= 11 && prio_mode <= 16) {    // quarters with a handicap: a YOUNGER workgroup (higher wave slot on its SIMD) leaves every level later,
+            // i.e. is kept ahead -- inside a level the arbiter serves the older workgroups first, and the youngest ends last
+            const int slot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;
+            const int den = prio_mode == 11 ? 12 : (prio_mode == 12 ? 8 : (prio_mode == 13 ? 6 : (prio_mode == 14 ? 16 : (prio_mode == 15 ? 24 : 4))));
+            const int pnum = gg * den - slot * Tsteps_x;               // (g - slot * T / den) * den
+            q = pnum <= 0 ? 0 : (pnum * 4) / (Tsteps_x * den);
+        }
         if (prio_mode == 9) { const int q8 = (gg * 8) / Tsteps_x; q = (q8 >> 1) + ((q8 & 1) & (gg & 1)); }                   // eighths: the odd ones alternate between two levels
         if (prio_mode == 10) { const int q16 = (gg * 16) / Tsteps_x; q = (q16 >> 2) + (((gg & 3) < (q16 & 3)) ? 1 : 0); }      // sixteenths, dithered over four steps
         if (q > 3) q = 3;
@@ -127,6 +135,28 @@ k = k.replace(old, old + """    const int Tsteps_x = (nblocks - 1) * S + last_su
 assert k.count("\n                g++;\n") == 1 and k.count("\n            g++;\n") == 1
 k = k.replace("\n                g++;\n", "\n                g++;\n                xprio(g);\n", 1)
 k = k.replace("\n            g++;\n", "\n            g++;\n            xprio(g);\n", 1)
+# ---- the prologue in the timeline: four marks in the V waves (entry of the prologue, first loads requested, sub-block 0 staged = its
+# loads have arrived, second loads requested), two in the H waves; the first mark of the loops then closes the prologue barrier
+old = "    if (role == 1) {\n        prefetch(0, 0, SS::pairs(0));\n        stage(sbase, SS::pairs(0));\n"
+assert old in k
+k = k.replace(old, "    if (role == 1) {\n        TMARK();\n        prefetch(0, 0, SS::pairs(0));\n        TMARK();\n        stage(sbase, SS::pairs(0));\n        TMARK();\n", 1)
+old = "        else if (exists(1, 0)) prefetch(1, 0, SS::pairs(0));\n    }\n    __syncthreads();\n"
+assert old in k
+k = k.replace(old, "        else if (exists(1, 0)) prefetch(1, 0, SS::pairs(0));\n        TMARK();\n    } else { TMARK(); TMARK(); }\n    __syncthreads();\n", 1)
+# ---- fifth experiment (LP): row-pair pitch of 16 bytes mod 32 and an H wave that takes TWO row pairs at once (even lanes one, odd
+# lanes the other): the sixteen lanes the LDS serves together then read sixteen different 16-byte bank groups -- no 2-way conflict
+k = k.replace("int TV = 0, int TR = 0>", "int TV = 0, int TR = 0, int LP = 0>")
+k = k.replace("    constexpr int BUF = G::NPS * G::PITCH * 2;    // floats per LDS buffer\n", "    constexpr int XP = G::PITCH + (LP ? 2 : 0);\n    constexpr int BUF = G::NPS * XP * 2;    // floats per LDS buffer\n", 1)
+assert "constexpr int XP" in k
+k = k.replace("G::PITCH", "XP").replace("constexpr int XP = XP + (LP ? 2 : 0);", "constexpr int XP = G::PITCH + (LP ? 2 : 0);")
+old = """        for (int task = tid; task < ((BLUR_ABL & 1) ? 0 : np * (NT / 2)); task += 64 * HW) {
+            const int rp = task / (NT / 2), t4 = task % (NT / 2);
+"""
+assert old in k
+k = k.replace(old, """        for (int task = tid; task < ((BLUR_ABL & 1) ? 0 : (LP ? 2 * NT : np * (NT / 2))); task += 64 * HW) {
+            const int rp = LP ? 2 * (tid >> 6) + (tid & 1) : task / (NT / 2), t4 = LP ? ((tid & 63) >> 1) + 32 * (task / (64 * HW)) : task % (NT / 2);
+            if (LP && rp >= np) continue;
+""", 1)
 hdr = '''// dev: GENERATED by tools/ubench/gen_blur_team_x.py from sift_pyocl_amd/csrc/k_pyramid.hpp -- the product's blur_team_kernel,
 // verbatim, plus a start-up stagger between the workgroups of a CU (stagger_mode / stagger_units).
 #pragma once

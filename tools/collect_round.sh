@@ -15,6 +15,9 @@ python tools/stage_profile.py 4096 smooth 0 > $OUT/stage_smooth4096.txt 2>&1
 bash tools/dev/trace_gaps.sh > $OUT/timeline_white4096.txt 2>&1
 for k in descriptor_kernel orientation_kernel; do bash tools/dev/pmc_split.sh $k > $OUT/pmc_$k.txt 2>&1; done   # (group 0, group 1) launches apart
 bash tools/dev/pmc_kernel.sh extrema_kernel > $OUT/pmc_extrema_kernel.txt 2>&1
+bash tools/dev/pmc_blur.sh > $OUT/pmc_blur_team_kernel.txt 2>&1                 # the dominant kernel: wait / issue / LDS counters per template instance
+[ -x tools/ubench/valu2_bench ] && ./tools/ubench/valu2_bench > $OUT/valu2.txt 2>&1   # v_sad / f64 / dot4 issue rates (tools/ubench/valu2.hip)
+[ -x tools/ubench/blur_var_bench ] && ./tools/ubench/blur_var_bench 4096 4096 384 > $OUT/blur_timeline.txt 2>&1   # per-wave timeline of the blur launches, priority feedback off / on
 python tools/bench_match.py > $OUT/match_100k.txt 2>&1
 python tools/dev/quick_smooth.py > $OUT/configs.txt 2>&1
 python tools/dev/small_frames.py tail 1 0 sizes=256,512,1024,2048 > $OUT/small_frames.txt 2>&1

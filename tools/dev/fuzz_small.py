@@ -30,6 +30,9 @@ for it in range(n):
     # option "split" needs the unforked chain --, every fifth deals the tiles in plain workgroup order)
     if it % 8 == 7: plan.set_option("split", 1)
     if it % 5 == 4: plan.set_option("xcd_map", 0)
+    # (round 6: the marching blur's priority feedback forced on every launch / off in a third of the cases each)
+    if it % 3 == 1: plan.set_option("march_prio", 2)
+    if it % 3 == 2: plan.set_option("march_prio", 0)
     got = plan.keypoints(img)
     assert_same_keypoints(got, want, "fuzz %d %dx%d %s" % (it, H, W, np.dtype(dt).name))
     assert_same_keypoints(plan.keypoints(img), want, "fuzz %d second call" % it)

@@ -157,6 +157,32 @@ k = k.replace(old, """        for (int task = tid; task < ((BLUR_ABL & 1) ? 0 : 
             const int rp = LP ? 2 * (tid >> 6) + (tid & 1) : task / (NT / 2), t4 = LP ? ((tid & 63) >> 1) + 32 * (task / (64 * HW)) : task % (NT / 2);
             if (LP && rp >= np) continue;
 """, 1)
+# ---- sixth experiment (PL): the first accumulator period peeled -- march row r < N - 1 feeds only the windows that start inside the
+# segment (taps j <= r): VPASSF is VPASS with those additions (and the products nobody needs) left out, used for block 0's sub-blocks
+k = k.replace("int TR = 0, int LP = 0>", "int TR = 0, int LP = 0, int PL = 0>")
+a = k.index("#define VPASS(sbuf, blk_, sub_)")
+b = k.index("    // step (blk, sub) exists?")
+macro = k[a:b]
+f = macro.replace("#define VPASS(sbuf, blk_, sub_)", "#define VPASSF(sbuf, blk_, sub_)")
+old1 = "                            if (k == 0) acc[slot_a] = (f32x2){0.f, 0.f} + prod;"
+assert old1 in f
+f = f.replace(old1, "                            if (k <= kk) { if (k == 0) acc[slot_a] = (f32x2){0.f, 0.f} + prod;")
+old2 = "                            asm volatile(\"\" : \"+v\"(acc[slot_a]));"
+assert old2 in f
+f = f.replace(old2, "                            asm volatile(\"\" : \"+v\"(acc[slot_a])); }")
+old3 = "                            if (k != N - 1 - k) { acc[slot_b]"
+assert old3 in f
+f = f.replace(old3, "                            if (k != N - 1 - k && (N - 1 - k) <= kk) { acc[slot_b]")
+old4 = "                            const f32x2 prod = h * t2;"
+assert old4 in f
+f = f.replace(old4, "                            f32x2 prod = {0.f, 0.f}; if (k <= kk || (N - 1 - k) <= kk) prod = h * t2;")
+k = k[:b] + f + k[b:]
+old = "                if (sub == 0) { VPASS(prev, blk - 1, S - 1) } else { VPASS(prev, blk, (sub + S - 1) % S) }\n"
+assert old in k
+k = k.replace(old, """                if (sub == 0) { if (PL && blk == 1) { VPASSF(prev, 0, S - 1) } else { VPASS(prev, blk - 1, S - 1) } }
+                else { if (PL && blk == 0) { VPASSF(prev, 0, (sub + S - 1) % S) } else { VPASS(prev, blk, (sub + S - 1) % S) } }
+""", 1)
+k = k.replace("#undef VPASS\n", "#undef VPASS\n#undef VPASSF\n", 1)
 hdr = '''// dev: GENERATED by tools/ubench/gen_blur_team_x.py from sift_pyocl_amd/csrc/k_pyramid.hpp -- the product's blur_team_kernel,
 // verbatim, plus a start-up stagger between the workgroups of a CU (stagger_mode / stagger_units).
 #pragma once

@@ -99,7 +99,7 @@ int siftmi_plan_tail_timeouts(const siftmi_plan *plan, int64_t *timeouts, int32_
 int siftmi_plan_set_params(siftmi_plan *plan, const siftmi_params *params);
 /* Tuning / diagnostic option of one plan by name (the reference's counterparts are constructor keywords such as
  * max_workgroup_size, plan.py:117-131).  Results never depend on an option.  Unknown name -> SIFTMI_EINVAL.  Names:
- *   launch shapes      "march", "march_wgs", "xcd_map" (marching blur, extrema: every XCD takes a contiguous range of tiles; default 1), "march_prio" (marching blur of 15 taps and more: wave priority falls with a workgroup's progress; default 1), "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
+ *   launch shapes      "march", "march_wgs", "xcd_map" (marching blur, extrema: every XCD takes a contiguous range of tiles; default 1), "march_prio" (marching blur: wave priority falls with a workgroup's progress -- 0 never, 1 = default: launches of about three workgroups per CU and the later octaves' chains, 2 every launch), "mm_blocks", "mm_threads", "ext_rows", "ext_strips",
  *                      "ori_blocks", "ori_small_blocks", "ori_pad", "ori_team", "desc_blocks", "desc_small_blocks", "desc_early_blocks",
  *                      "desc_dense_blocks", "desc_pad", "desc_team", "desc_dynamic", "desc_stream", "maps_blocks"
  *   kernel forms       "fused_convert", "fused_shrink", "fused_refine", "tail", "tail_pixels",

@@ -91,6 +91,12 @@ def test_descriptor_kernel_forms_agree(siftlib, oracle):
     assert_same_keypoints(plan.keypoints(img), want, "gradient maps, one stream")
     plan.set_option("overlap", 1)
     plan.set_option("maps", 2)
+    # round 6: the marching blur's priority feedback ("march_prio": never / by rule / every launch) does not touch a result
+    for v in (0, 2, 1):
+        plan.set_option("march_prio", v)
+        assert_same_keypoints(plan.keypoints(img), want, "march_prio %d" % v)
+    with pytest.raises(RuntimeError):
+        plan.set_option("march_prio", 3)
     plan.pinned_results = False                                  # plain numpy result + device-to-host copy
     assert_same_keypoints(plan.keypoints(img), want, "unpinned result array")
     for init_sigma in (3.0, 4.0):

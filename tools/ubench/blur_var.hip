@@ -321,6 +321,26 @@ template <int N, int S> void run(const float *in, float *o1, float *o2, int W, i
     }
 }
 
+// the product kernel with other sub-block counts S (rows per step), priority feedback on: has the best S moved?
+template <int N, int S> void subsplit(const float *in, float *o1, int W, int H) {
+    using G = March2Geom<N, 128, S>;
+    using SS = SubSplit<N, S>;
+    auto tv = gauss(N, 0.125f * N);
+    TapsArg<N> ta;
+    for (int i = 0; i < N; i++) ta.t[i] = tv[i];
+    const size_t lds = (size_t)3 * G::LDS_BYTES;
+    for (int wgs : {640, 768, 896, 1024}) {
+        const Geo g = geometry<N, S>(W, H, wgs);
+        if (lds > 64 * 1024) { printf("  N %2d S %d: %zu bytes of LDS per workgroup: skipped\n", N, S, lds); return; }
+        for (int prio = 1; prio < 2; prio++) {
+            auto ref = [&] { hipLaunchKernelGGL((blur_team_kernel<N, false, S, 0, 2>), dim3(g.gx, g.gy), dim3(256), lds, 0, (const void *)in, o1, W, H, g.nblocks, g.last_subs,
+                                                g.rows_out, ta, (const uint32_t *)nullptr, (float *)nullptr, 1, prio); };
+            const float t = timeit(ref);
+            printf("  N %2d S %d (%d rows per step, %d row pairs, LDS %5zu B) wgs %4d prio %d  %7.2f us\n", N, S, SS::RB, G::NPS, lds, g.gx * g.gy, prio, t);
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     const int W = argc > 1 ? atoi(argv[1]) : 4096, H = argc > 2 ? atoi(argv[2]) : 4096;
     const int which = argc > 3 ? atoi(argv[3]) : 7;
@@ -333,6 +353,17 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < h.size(); i++) { st = st * 1664525u + 1013904223u; h[i] = (float)(st >> 8) * (255.0f / 16777216.0f); }
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     printf("plane %d x %d, xcd_map 1; times: one launch inside a train of 10, best of 5 trains\n", W, H);
+    if (which & 2048) {
+        for (int pass = 0; pass < 3; pass++) {
+            subsplit<11, 1>(in, o1, W, H); subsplit<11, 2>(in, o1, W, H);
+            subsplit<15, 2>(in, o1, W, H); subsplit<15, 3>(in, o1, W, H);
+            subsplit<17, 2>(in, o1, W, H); subsplit<17, 3>(in, o1, W, H);
+            subsplit<21, 2>(in, o1, W, H); subsplit<21, 3>(in, o1, W, H); subsplit<21, 4>(in, o1, W, H);
+            subsplit<27, 2>(in, o1, W, H); subsplit<27, 4>(in, o1, W, H);
+            printf("---- second pass\n");
+        }
+        return 0;
+    }
     for (int pass = 0; pass < 2; pass++) {            // the first pass warms the clocks (and is printed: compare)
         run<11, 2>(in, o1, o2, W, H, which);
         run<15, 2>(in, o1, o2, W, H, which);

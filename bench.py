@@ -156,7 +156,7 @@ def spawn_ranks(args):
 
 
 # ---- VALU roofline (round 4).  Issue intervals per wave-instruction and SIMD, measured on this chip with
-# tools/ubench/valu_rate.hip (profiles/r04/valu_issue_rate.txt; 8 waves per SIMD, 8 independent chains, shader clock read
+# tools/ubench/valu_rate.hip (profiles/r06/valu_issue_rate.txt; 8 waves per SIMD, 8 independent chains, shader clock read
 # beside it): plain f32 add / mul / fma and u32 add / sub / logic / right shifts / v_mov 2.4 cycles; every other class
 # (packed f32, f64, conversions, compares, selects, left shifts, 3-operand integer ops, DPP, mbcnt, v_sad) 4.2; f32
 # transcendentals 8.2, f64 ones 16.2.  The hardware guide's "2 cycles per wave64 op" holds for the first class only.
@@ -202,7 +202,7 @@ def roofline_valu(ms_per_step):
             "issue_ms_if_all_half_rate": round(instr * 4.2 / (VALU_SIMDS * VALU_CLOCK_GHZ * 1e9) * 1e3, 4),
             "simds": VALU_SIMDS, "clock_ghz": VALU_CLOCK_GHZ, "cycles_per_class": VALU_CYCLES,
             "source": "instruction counts replayed from %s (rocprofv3 --pmc SQ_INSTS_VALU* of this command, tools/valu_frame.sh); "
-                      "issue intervals from profiles/r04/valu_issue_rate.txt (tools/ubench/valu_rate.hip); fingerprint of the library's "
+                      "issue intervals from profiles/r06/valu_issue_rate.txt (tools/ubench/valu_rate.hip); fingerprint of the library's "
                       "sources %s = the loaded one" % (rel, library_fingerprint())}
 
 

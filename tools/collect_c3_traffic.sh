@@ -1,8 +1,8 @@
 #!/bin/bash
 # HBM traffic of the full-resolution blur launches at 16384^2 (BASELINE configs[2]: planes of 1 GiB, nothing fits the
 # Infinity Cache): kernel trace + the two PMC passes of `bench.py --size 16384 --octaves 0`, summarised like the headline's.
-# Usage (GPU box, repo root):  bash tools/collect_c3_traffic.sh r05   ->  gpurun_out/prof_c3_<tag>/{summary.txt, blur_traffic.json}
-TAG=${1:-r05}
+# Usage (GPU box, repo root):  bash tools/collect_c3_traffic.sh r06   ->  gpurun_out/prof_c3_<tag>/{summary.txt, blur_traffic.json}
+TAG=${1:-r06}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_c3_$TAG
 rm -rf $OUT; mkdir -p $OUT

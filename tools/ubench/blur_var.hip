@@ -146,6 +146,20 @@ template <int N, int S, int PL> void peel(const float *in, float *o2, int W, int
            100.0 * (t - t_ref) / t_ref, same ? "bitwise equal" : "MISMATCH");
 }
 
+template <int N, int S, int X2> void wideload(const float *in, float *o2, int W, int H, const TapsArg<N> &ta, int wgs, float t_ref, int prio) {
+    using G = March2Geom<N, 128, S>;
+    const Geo g = geometry<N, S>(W, H, wgs);
+    const size_t lds = (size_t)3 * G::LDS_BYTES;
+    hipMemset(o2, 0xff, (size_t)W * H * 4);
+    auto launch = [&] { hipLaunchKernelGGL((blur_team_x<N, false, S, 0, 2, 0, 0, 0, 0, X2>), dim3(g.gx, g.gy), dim3(256), lds, 0, (const void *)in, o2, W, H, g.nblocks,
+                                           g.last_subs, g.rows_out, ta, (const uint32_t *)nullptr, (float *)nullptr, 1, prio, 0, 0, (unsigned long long *)nullptr, 0); };
+    const float t = timeit(launch);
+    size_t bad;
+    const bool same = same_as_ref(o2, (size_t)W * H, &bad);
+    printf("  N %2d  product (prio %d)%s   wgs %4d  %7.2f us  (%+5.1f %%)  %s\n", N, prio, X2 ? " + 8-byte main loads, 16-byte staging" : "", g.gx * g.gy, t,
+           100.0 * (t - t_ref) / t_ref, same ? "bitwise equal" : "MISMATCH");
+}
+
 template <int N, int S> void stagger(const float *in, float *o2, int W, int H, const TapsArg<N> &ta, int wgs, float t_ref, int mode, int units) {
     using G = March2Geom<N, 128, S>;
     const Geo g = geometry<N, S>(W, H, wgs);
@@ -301,6 +315,7 @@ template <int N, int S> void run(const float *in, float *o1, float *o2, int W, i
     if (which & 4) {
         variant<N, S, 2, 2>("front loads, D=2, clock", in, o2, W, H, ta, wgs0, t_ref);
     }
+    if (which & 4096) { for (int rep = 0; rep < 3; rep++) { wideload<N, S, 0>(in, o2, W, H, ta, wgs0, t_ref, 1); wideload<N, S, 1>(in, o2, W, H, ta, wgs0, t_ref, 1); } }
     if (which & 1024) { for (int rep = 0; rep < 2; rep++) { peel<N, S, 0>(in, o2, W, H, ta, wgs0, t_ref, 1); peel<N, S, 1>(in, o2, W, H, ta, wgs0, t_ref, 1); } }
     if (which & 512) { for (int rep = 0; rep < 2; rep++) { ldspitch<N, S, 0>(in, o2, W, H, ta, wgs0, t_ref, 1); ldspitch<N, S, 1>(in, o2, W, H, ta, wgs0, t_ref, 1); } }
     if (which & 256) { for (int mode : {0, 1, 3, 4, 9, 11, 1, 0}) prio<N, S>(in, o2, W, H, ta, wgs0, t_ref, mode); }

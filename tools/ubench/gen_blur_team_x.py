@@ -183,6 +183,43 @@ k = k.replace(old, """                if (sub == 0) { if (PL && blk == 1) { VPAS
                 else { if (PL && blk == 0) { VPASSF(prev, 0, (sub + S - 1) % S) } else { VPASS(prev, blk, (sub + S - 1) % S) } }
 """, 1)
 k = k.replace("#undef VPASS\n", "#undef VPASS\n#undef VPASSF\n", 1)
+# ---- eighth experiment (X2): the 256 main columns of a sub-block row loaded as one 8-byte load per lane (columns 2t, 2t + 1) instead of
+# two 4-byte loads (columns t, 128 + t), staged with one 16-byte LDS write per row pair instead of two 8-byte ones -- where the strip
+# and the rows lie inside the plane (the reflecting path keeps the scalar loads)
+k = k.replace("int LP = 0, int PL = 0>", "int LP = 0, int PL = 0, int X2 = 0>")
+old = "    f32x2 pa[G::NPS], pb[G::NPS], ph[G::NB];\n"
+assert old in k
+k = k.replace(old, old + "    typedef float f32x2_u4 __attribute__((ext_vector_type(2), aligned(4)));\n    bool wide = false;             // the look-ahead registers hold (row 0: columns 2t, 2t+1 | row 1: the same columns)\n    const bool strip_inside = X2 && (x0 - G::C >= 0) && (x0 - G::C + G::TX <= W);\n", 1)
+old = """        if (v0 >= 0 && v0 + 2 * np <= H) {
+            unsigned oa = ((unsigned)v0 * (unsigned)W + (unsigned)gx_a) * 4u;"""
+assert old in k
+k = k.replace(old, """        wide = false;
+        if (X2 && strip_inside && v0 >= 0 && v0 + 2 * np <= H) {
+            wide = true;
+            const char *base = reinterpret_cast<const char *>(in) + ((size_t)v0 * W + (x0 - G::C + 2 * tid)) * 4;
+#pragma unroll
+            for (int rp = 0; rp < G::NPS; rp++)
+                if (rp < np) {
+                    pa[rp] = *reinterpret_cast<const f32x2_u4 *>(base);
+                    pb[rp] = *reinterpret_cast<const f32x2_u4 *>(base + W4);
+                    base += 2u * W4;
+                }
+        } else if (v0 >= 0 && v0 + 2 * np <= H) {
+            unsigned oa = ((unsigned)v0 * (unsigned)W + (unsigned)gx_a) * 4u;""", 1)
+old = """            if (rp < np) {
+                *reinterpret_cast<f32x2 *>(s + (rp * XP + tid) * 2) = norm2(pa[rp]);
+                *reinterpret_cast<f32x2 *>(s + (rp * XP + NT + tid) * 2) = norm2(pb[rp]);
+            }"""
+assert old in k, "stage"
+k = k.replace(old, """            if (rp < np) {
+                if (X2 && wide) {
+                    const f32x2 a = norm2(pa[rp]), b = norm2(pb[rp]);
+                    *reinterpret_cast<f32x4 *>(s + (rp * XP + 2 * tid) * 2) = (f32x4){a.x, b.x, a.y, b.y};
+                } else {
+                    *reinterpret_cast<f32x2 *>(s + (rp * XP + tid) * 2) = norm2(pa[rp]);
+                    *reinterpret_cast<f32x2 *>(s + (rp * XP + NT + tid) * 2) = norm2(pb[rp]);
+                }
+            }""", 1)
 hdr = '''// dev: GENERATED by tools/ubench/gen_blur_team_x.py from sift_pyocl_amd/csrc/k_pyramid.hpp -- the product's blur_team_kernel,
 // verbatim, plus a start-up stagger between the workgroups of a CU (stagger_mode / stagger_units).
 #pragma once
